@@ -1,0 +1,329 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures by IMPORTING the reference (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+The reference (/root/reference, mbzuai-metaverse/XMem2) has no tests and no golden
+vectors of its own, so parity of this path is pinned by running
+the reference's own modules here on seeded inputs and committing the outputs as small
+``.npz`` fixtures.  While generating, every scenario is also run through the oracle
+(``oracle/cpu_ref.py``) and asserted BIT-EQUAL to the reference (same process, same
+thread count) - that is the check that pins the oracle.
+
+Nothing of the reference's source travels: the fixtures hold inputs/outputs only.
+Work-arounds: InferenceCore.__init__ touches cuda:0, so it is bypassed
+by a harness subclass; XMem is built with pretrained_*=False and model_path=None; the
+weights are this repo's conditioned synthetic state_dict (xmem2_amd/synth.py).
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+
+THREADS = 1
+torch.set_num_threads(THREADS)
+torch.set_grad_enabled(False)
+
+from oracle import cpu_ref as R                                   # noqa: E402
+from xmem2_amd.synth import (synthetic_state_dict, synthetic_frames, synthetic_masks,  # noqa: E402
+                             hash_normal, hash_uniform)
+
+from model import memory_util as ref_mu                          # noqa: E402  (reference)
+from model.network import XMem as RefXMem                        # noqa: E402
+from model.aggregate import aggregate as ref_aggregate           # noqa: E402
+from inference.memory_manager import MemoryManager as RefMM      # noqa: E402
+from inference.inference_core import InferenceCore as RefIC      # noqa: E402
+from inference.data.mask_mapper import MaskMapper as RefMapper   # noqa: E402
+from util import tensor_util as ref_tu                           # noqa: E402
+
+META = dict(threads=THREADS, torch=torch.__version__, reference='mbzuai-metaverse/XMem2 @ 2025-02-11')
+
+
+def beq(a, b, what):
+    if a is None and b is None:
+        return
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.equal(a, b), f'oracle != reference (bitwise) at {what}: max|d|={float((a - b).abs().max())}'
+
+
+def rnd(shape, stream, scale=1.0):
+    return torch.from_numpy(hash_normal(int(np.prod(shape)), stream).reshape(shape) * np.float32(scale))
+
+
+def uni(shape, stream, lo, hi):
+    return torch.from_numpy(hash_uniform(int(np.prod(shape)), stream, lo, hi).reshape(shape))
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.numpy()
+        out[k] = v
+    out['meta'] = np.array(repr(META))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'  wrote {name}.npz  {os.path.getsize(path) / 1e6:.2f} MB')
+
+
+class HarnessCore(RefIC):
+    """Reference InferenceCore without the cuda:0 warm-up (inference_core.py:13-23 only)."""
+
+    def __init__(self, network, config):
+        self.config = config
+        self.network = network
+        self.mem_every = config['mem_every']
+        self.deep_update_every = config['deep_update_every']
+        self.enable_long_term = config['enable_long_term']
+        self.deep_update_sync = (self.deep_update_every < 0)
+        self.clear_memory()
+        self.all_labels = None
+
+
+def base_config(**over):
+    cfg = dict(mem_every=10, deep_update_every=-1, enable_long_term=True, enable_long_term_count_usage=True,
+               hidden_dim=64, key_dim=64, value_dim=512, top_k=30, max_mid_term_frames=10, min_mid_term_frames=5,
+               num_prototypes=128, max_long_term_elements=10000)
+    cfg.update(over)
+    return cfg
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_ops():
+    print('L-op: get_similarity / do_softmax / readout')
+    for tag, (n, hw, ck, cv) in {'small': (64, 40, 64, 32), 'mid': (1215, 405, 64, 64)}.items():
+        s0 = {'small': 100, 'mid': 200}[tag]
+        mk = rnd((1, ck, n), s0 + 1, 0.9)
+        ms = uni((1, 1, n), s0 + 2, 1.0, 4.0)
+        qk = rnd((1, ck, hw), s0 + 3, 0.9)
+        qe = uni((1, ck, hw), s0 + 4, 0.05, 0.95)
+        mv = rnd((2, cv, n), s0 + 5)
+        out = dict(mk=mk, ms=ms, qk=qk, qe=qe, mv=mv)
+        for vname, (s_, e_) in {'se': (ms, qe), 's': (ms, None), 'e': (None, qe), 'none': (None, None)}.items():
+            ref = ref_mu.get_similarity(mk, s_, qk, e_)
+            beq(R.get_similarity(mk, s_, qk, e_), ref, f'get_similarity[{vname}]')
+            out['sim_' + vname] = ref
+        sim = out['sim_se']
+        aff, usage = ref_mu.do_softmax(sim.clone(), top_k=30, inplace=True, return_usage=True)
+        aff_o, usage_o = R.do_softmax(sim.clone(), top_k=30, inplace=True, return_usage=True)
+        beq(aff_o, aff, 'do_softmax topk'); beq(usage_o, usage, 'usage')
+        w, idx = R.topk_softmax_sparse(sim, 30)
+        dense = torch.zeros_like(sim).scatter_(1, idx, w)
+        beq(dense, aff, 'sparse form == dense affinity')
+        full = ref_mu.do_softmax(sim.clone())
+        beq(R.do_softmax(sim.clone()), full, 'do_softmax full')
+        ro = mv @ aff                                      # memory_manager.py:57-59
+        out.update(topk_w=w, topk_idx=idx.to(torch.int32), usage=usage, readout=ro,
+                   full_softmax_colsum=full.sum(1), full_softmax_sample=full[:, ::7, ::5].contiguous())
+        del out['sim_s'], out['sim_e'], out['sim_none']
+        out['sim_s_sample'] = ref_mu.get_similarity(mk, ms, qk, None)[:, ::7, ::5].contiguous()
+        out['sim_e_sample'] = ref_mu.get_similarity(mk, None, qk, qe)[:, ::7, ::5].contiguous()
+        out['sim_none_sample'] = ref_mu.get_similarity(mk, None, qk, None)[:, ::7, ::5].contiguous()
+        if tag == 'mid':
+            out['sim_se'] = out['sim_se'][:, ::7, ::5].contiguous()   # keep the fixture small
+        save('op_' + tag, **out)
+
+
+# ----------------------------------------------------------------------------------------------
+def _feed(mm, step, kind, objects, hw_shape, n_obj, ti=None):
+    """Synthetic key/shrinkage/value/selection for scripted memory sequences (both sides get the same tensors)."""
+    h, w = hw_shape
+    key = rnd((1, 64, h, w), 5000 + step * 10 + 1, 0.9)
+    shr = uni((1, 1, h, w), 5000 + step * 10 + 2, 1.0, 4.0)
+    sel = uni((1, 64, h, w), 5000 + step * 10 + 3, 0.05, 0.95)
+    val = rnd((1, n_obj, 128, h, w), 5000 + step * 10 + 4)
+    return key, shr, val, sel
+
+
+def gen_memory():
+    print('L-mem: scripted MemoryManager sequences')
+    h, w = 8, 12
+    hw = h * w
+
+    def run(script, cfg, tag):
+        ref, orc = RefMM(cfg), R.RefMemory(cfg)
+        rec = {}
+        for step, op in enumerate(script):
+            kind = op[0]
+            if kind in ('perm', 'temp'):
+                objects, ti = op[1], (op[2] if len(op) > 2 else None)
+                key, shr, val, sel = _feed(None, step, kind, objects, (h, w), len(objects))
+                for m in (ref, orc):
+                    m.add_memory(key.clone(), shr.clone(), val.clone(), list(objects), selection=sel.clone(),
+                                 permanent=(kind == 'perm'), ti=ti)
+            elif kind == 'replace':
+                ti, n_obj = op[1], op[2]
+                key, shr, val, sel = _feed(None, step, kind, None, (h, w), n_obj)
+                for m in (ref, orc):
+                    m.update_permanent_memory(ti, key.clone(), shr.clone(), val.clone(), selection=sel.clone())
+            elif kind == 'match':
+                qk = rnd((1, 64, h, w), 9000 + step * 10 + 1, 0.9)
+                qe = uni((1, 64, h, w), 9000 + step * 10 + 2, 0.05, 0.95)
+                r = ref.match_memory(qk.clone(), qe.clone())
+                beq(orc.match_memory(qk.clone(), qe.clone()), r, f'{tag} match@{step}')
+                rec[f'readout_{step}'] = r
+                if ref.temporary_work_mem.size > 0:
+                    rec[f'tmp_use_{step}'] = ref.temporary_work_mem.use_count.clone()
+                    rec[f'tmp_life_{step}'] = ref.temporary_work_mem.life_count.clone()
+                    beq(orc.temporary_work_mem.use_count, ref.temporary_work_mem.use_count, 'use_count')
+                if ref.long_mem.engaged() and ref.enable_long_term_usage:
+                    rec[f'lt_use_{step}'] = ref.long_mem.use_count.clone()
+            sizes = (ref.temporary_work_mem.size, ref.permanent_work_mem.size, ref.long_mem.size)
+            assert sizes == (orc.temporary_work_mem.size, orc.permanent_work_mem.size, orc.long_mem.size)
+            rec[f'sizes_{step}'] = np.array(sizes, np.int64)
+            rec[f'vsizes_{step}'] = np.array(
+                [[st.get_v_size(g) if g < st.num_groups else -1 for g in range(2)]
+                 for st in (ref.temporary_work_mem, ref.permanent_work_mem, ref.long_mem)], np.int64)
+        if ref.long_mem.engaged():
+            beq(orc.long_mem.key, ref.long_mem.key, 'lt key'); beq(orc.long_mem.shrinkage, ref.long_mem.shrinkage, 'lt shr')
+            rec['lt_key'] = ref.long_mem.key.clone(); rec['lt_shrinkage'] = ref.long_mem.shrinkage.clone()
+            for g, gv in enumerate(ref.long_mem.value):
+                beq(orc.long_mem.value[g], gv, 'lt value'); rec[f'lt_value_{g}'] = gv.clone()
+        rec['script'] = np.array(repr(script)); rec['config'] = np.array(repr(cfg)); rec['hw'] = np.array([h, w])
+        save('mem_' + tag, **rec)
+
+    cfg = base_config(max_mid_term_frames=4, min_mid_term_frames=2, num_prototypes=32)
+    # A: one object group; permanent add + replace; temp adds until two consolidations
+    script_a = [('perm', [1], 0), ('match',), ('perm', [1], 7), ('match',), ('replace', 0, 1), ('match',)]
+    for _ in range(7):
+        script_a += [('temp', [1]), ('match',), ('match',)]
+    run(script_a, cfg, 'single_group')
+    # B: a second object group appears later (suffix alignment), consolidation with a partial group
+    script_b = [('perm', [1], 0), ('match',), ('temp', [1]), ('match',), ('perm', [1, 2], 5), ('match',)]
+    for _ in range(6):
+        script_b += [('temp', [1, 2]), ('match',), ('match',)]
+    run(script_b, cfg, 'two_groups')
+    # C: long-term eviction (remove_obsolete_features), single group
+    cfg_c = base_config(max_mid_term_frames=3, min_mid_term_frames=1, num_prototypes=32, max_long_term_elements=100)
+    script_c = [('perm', [1], 0), ('match',)]
+    for _ in range(12):
+        script_c += [('temp', [1]), ('match',)]
+    run(script_c, cfg_c, 'lt_eviction')
+
+
+# ----------------------------------------------------------------------------------------------
+def build_ref_net(sd):
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = RefXMem(base_config(), None, pretrained_key_encoder=False, pretrained_value_encoder=False).eval()
+    net.load_state_dict(sd)
+    return net
+
+
+def gen_net(sd, ref_net):
+    print('L-net: encode_key / encode_value / segment')
+    orc = R.RefNet(sd)
+    hh, ww, k = 96, 128, 2
+    frame = torch.from_numpy(synthetic_frames(1, hh, ww, seed=77)[0])[None]
+    masks = torch.from_numpy(synthetic_masks(1, k, hh, ww)[0])[None]
+    key, shr, sel, f16, f8, f4 = ref_net.encode_key(frame)
+    for a, b, n in zip(orc.encode_key(frame), (key, shr, sel, f16, f8, f4), 'key shr sel f16 f8 f4'.split()):
+        beq(a, b, 'encode_key.' + n)
+    hidden0 = rnd((1, k, 64, hh // 16, ww // 16), 4242, 0.3)
+    prob = ref_aggregate(masks[0], dim=0)
+    beq(R.aggregate(masks[0], dim=0), prob, 'aggregate')
+    val, hid_v = ref_net.encode_value(frame, f16, hidden0, prob[1:].unsqueeze(0), is_deep_update=True)
+    val_o, hid_o = orc.encode_value(frame, f16, hidden0, prob[1:].unsqueeze(0), is_deep_update=True)
+    beq(val_o, val, 'encode_value.value'); beq(hid_o, hid_v, 'encode_value.hidden')
+    readout = rnd((1, k, 512, hh // 16, ww // 16), 4343, 0.4)
+    hid_s, logits, pr = ref_net.segment((f16, f8, f4), readout, hidden0, h_out=True, strip_bg=False)
+    hid_so, logits_o, pr_o = orc.segment((f16, f8, f4), readout, hidden0, h_out=True, strip_bg=False)
+    beq(hid_so, hid_s, 'segment.hidden'); beq(logits_o, logits, 'segment.logits'); beq(pr_o, pr, 'segment.prob')
+    save('net_96x128', frame=frame, masks=masks, hidden0=hidden0, readout=readout,
+         key=key, shrinkage=shr, selection=sel, f16=f16, f8=f8, f4=f4,
+         value=val, hidden_value=hid_v, hidden_seg=hid_s, logits=logits, prob=pr)
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_e2e(sd, ref_net):
+    print('L-e2e: InferenceCore.step over synthetic clips')
+    orc_net = R.RefNet(sd)
+
+    def run(tag, frames, masks, cfg, perm_frames, mask_frames, labels):
+        ref, orc = HarnessCore(ref_net, cfg), R.RefCore(orc_net, cfg)
+        for c in (ref, orc):
+            c.set_all_labels(list(labels))
+        for j in perm_frames:
+            fr, mk = torch.from_numpy(frames[j]), torch.from_numpy(masks[j])
+            ref.put_to_permanent_memory(fr.clone(), mk.clone())
+            orc.put_to_permanent_memory(fr.clone(), mk.clone())
+        t_all = frames.shape[0]
+        arg, psum, sizes, pds = [], [], [], []
+        for ti in range(t_all):
+            fr = torch.from_numpy(frames[ti])
+            mk = torch.from_numpy(masks[ti]) if ti in mask_frames else None
+            kw = dict(end=(ti == t_all - 1), do_not_add_mask_to_memory=(mk is not None))
+            lab = list(labels) if mk is not None else None
+            p_ref = ref.step(fr.clone(), mk.clone() if mk is not None else None, lab, **kw)
+            p_orc = orc.step(fr.clone(), mk.clone() if mk is not None else None, lab, **kw)
+            beq(p_orc, p_ref, f'{tag} step {ti}')
+            assert not torch.isnan(p_ref).any(), f'NaN at {tag} frame {ti}'
+            arg.append(torch.argmax(p_ref, dim=0).numpy().astype(np.uint8))
+            psum.append(p_ref.double().sum(dim=(1, 2)).numpy())
+            pds.append(p_ref[:, 4::8, 4::8].numpy().copy())
+            m = ref.memory
+            sizes.append([m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size])
+        top2 = None
+        save('e2e_' + tag, argmax=np.stack(arg), prob_sum=np.stack(psum), prob_ds8=np.stack(pds),
+             sizes=np.array(sizes, np.int64), config=np.array(repr(cfg)), perm_frames=np.array(perm_frames),
+             mask_frames=np.array(sorted(mask_frames)), labels=np.array(labels),
+             shape=np.array(frames.shape))
+        fr_obj = np.stack(arg)
+        print(f'    {tag}: object fractions per frame (first/last) '
+              f'{[(fr_obj[i] == l).mean().round(3) for i in (1, -1) for l in labels]}  final sizes {sizes[-1]}')
+
+    # clip A: 240x427 (pads to 240x432), 2 objects, consolidation exercised
+    t, hh, ww = 26, 240, 427
+    frames, masks = synthetic_frames(t, hh, ww), synthetic_masks(t, 2, hh, ww)
+    cfg = base_config(mem_every=3, max_mid_term_frames=4, min_mid_term_frames=2, num_prototypes=64)
+    run('240p_2obj', frames, masks, cfg, perm_frames=[0, 13], mask_frames={0, 13}, labels=[1, 2])
+    # clip B: 480x854 (the benchmark geometry), 1 object, default config, short
+    t, hh, ww = 5, 480, 854
+    frames, masks = synthetic_frames(t, hh, ww), synthetic_masks(t, 1, hh, ww)
+    run('480p_1obj', frames, masks, base_config(mem_every=2), perm_frames=[0], mask_frames={0}, labels=[1])
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_misc():
+    print('misc: pad/unpad, aggregate, MaskMapper, IoU')
+    x = rnd((3, 50, 70), 31)
+    p, pad = ref_tu.pad_divide_by(x, 16)
+    po, pado = R.pad_divide_by(x, 16)
+    beq(po, p, 'pad'); assert tuple(pad) == tuple(pado)
+    beq(R.unpad(po, pado), ref_tu.unpad(p, pad), 'unpad')
+    m = np.zeros((20, 30), np.uint8); m[2:8, 3:9] = 5; m[10:15, 10:20] = 2; m[16:19, 1:5] = 9
+    rm, om = RefMapper(), R.RefMaskMapper()
+    a1, l1 = rm.convert_mask(m, exhaustive=True); b1, k1 = om.convert_mask(m, exhaustive=True)
+    beq(b1, a1, 'mapper'); assert list(l1) == list(k1) and rm.remappings == om.remappings
+    m2 = m.copy(); m2[0:2, 0:2] = 7
+    a2, l2 = rm.convert_mask(m2, exhaustive=True); b2, k2 = om.convert_mask(m2, exhaustive=True)
+    beq(b2, a2, 'mapper2'); assert list(l2) == list(k2) and rm.remappings == om.remappings
+    idx = np.random.RandomState(0).randint(0, 5, (20, 30)).astype(np.uint8)
+    assert np.array_equal(rm.remap_index_mask(idx), om.remap_index_mask(idx))
+    seg = np.random.RandomState(1).randint(0, 3, (40, 50)).astype(np.uint8)
+    gt = np.random.RandomState(2).randint(0, 3, (40, 50)).astype(np.uint8)
+    iou = float(ref_tu.compute_array_iou(seg, gt)); assert abs(iou - R.compute_array_iou(seg, gt)) < 1e-7
+    save('misc', pad_in=x, pad_out=p, pad=np.array(pad), mask_in=m, mask_in2=m2, onehot1=a1, onehot2=a2,
+         labels1=np.array(list(l1)), labels2=np.array(list(l2)),
+         remap_keys=np.array(list(rm.remappings.keys())), remap_vals=np.array(list(rm.remappings.values())),
+         remap_in=idx, remap_out=rm.remap_index_mask(idx), iou_seg=seg, iou_gt=gt, iou=np.array(iou))
+
+
+if __name__ == '__main__':
+    gen_misc()
+    gen_ops()
+    gen_memory()
+    print('building conditioned synthetic weights ...')
+    sd = synthetic_state_dict(seed=0)
+    ref_net = build_ref_net(sd)
+    gen_net(sd, ref_net)
+    gen_e2e(sd, ref_net)
+    print('all scenarios: oracle bit-equal to the imported reference; fixtures written to', HERE)
