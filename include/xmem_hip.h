@@ -1,0 +1,215 @@
+/*
+ * xmem_hip.h - C-ABI of the MI355X (gfx950) kernels behind XMem++'s per-frame
+ * space-time memory path.
+ *
+ * The reference (mbzuai-metaverse/XMem2) has no FFI or operator registry: its hot
+ * path is a chain of stock ATen calls issued from Python.  This header is therefore
+ * the boundary a maintainer would bind in place of those ATen call sites; every
+ * entry point cites the reference lines it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     the name ends in _host;  `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success or a negative xmem_status code; nothing
+ *     throws across the ABI; no function allocates or frees caller-visible memory
+ *     (scratch is passed in, sized by the matching *_workspace_bytes function).
+ *   - no global mutable state: safe to call concurrently on different streams/devices.
+ *   - activations are NHWC fp32: [B][H][W][C] with an explicit pixel stride `ld*`
+ *     (in floats) so a tensor may live inside a wider (concatenated) buffer.
+ *   - memory elements are rows: keys [N][C_k], values [N][C_v], shrinkage [N].
+ */
+#ifndef XMEM_HIP_H
+#define XMEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    XMEM_OK = 0,
+    XMEM_ERR_BAD_ARG = -1,      /* null pointer / non-positive size / unsupported dimension */
+    XMEM_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels implement (message says which) */
+    XMEM_ERR_WORKSPACE = -3,    /* workspace too small */
+    XMEM_ERR_LAUNCH = -4,       /* hipLaunch / hipGetLastError failure */
+    XMEM_ERR_TOPK = -5          /* fewer memory elements than top_k (torch.topk raises, memory_util.py:46) */
+} xmem_status;
+
+int xmem_version(void);                       /* ABI version, currently 1 */
+const char* xmem_last_error_string(int code); /* static string for a status code */
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) with fused epilogue.
+ * Replaces nn.Conv2d (+ eval BatchNorm2d + ReLU + residual add) call sites:
+ *   model/resnet.py:59-75,95-114 (BasicBlock/Bottleneck), model/modules.py:166-175,
+ *   135-142, 207-211, 186-191, 229-250, model/group_modules.py:25-52 (GConv2D/GroupResBlock).
+ *
+ *   out[b,oh,ow,n] = act( (sum_{kh,kw,c} in'[b,oh*s-p+kh,ow*s-p+kw,c] * w[n,kh,kw,c]) * scale[n] + shift[n]
+ *                         + res[b,oh,ow,n] )
+ *   in' = relu(in) if relu_in.  scale/shift hold the folded BatchNorm (scale = gamma/sqrt(var+eps),
+ *   shift = beta - mean*scale) or (1, bias).  res may be NULL.  Weights are [Cout][KH][KW][Cin]
+ *   (Cin contiguous, Cin % 4 == 0; pad with zero channels if needed).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* in;    int B, H, W, Cin, ldin;
+    const float* w;     int Cout, KH, KW, stride, pad;
+    const float* scale; const float* shift;
+    const float* res;   int ldres;
+    float* out;         int ldout;
+    int relu_in, relu_out;
+} xmem_conv_desc;
+
+size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);
+int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling / resampling / gating kernels of the encoders and the decoder.
+ * ------------------------------------------------------------------------------------------ */
+/* nn.MaxPool2d(3, stride 2, pad 1), model/resnet.py:123; in [B][H][W][C] -> out [B][Ho][Wo][C] */
+int xmem_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, void* stream);
+
+/* F.interpolate(scale 2, bilinear, align_corners=False) of g [B][h][w][C] plus the broadcast skip
+ * feature [2h][2w][C]: UpsampleBlock, model/modules.py:186-190 + group_modules.py:15-23 */
+int xmem_upsample2x_add(const float* g, const float* skip, float* out, int B, int h, int w, int C, void* stream);
+
+/* F.interpolate(mode='area') by an integer ratio r (2 or 4), group_modules.py:22-23;
+ * in [B][H][W][C] (pixel stride ldin) -> out [B][H/r][W/r][C] (pixel stride ldout) */
+int xmem_area_downsample(const float* in, int ldin, float* out, int ldout, int B, int H, int W, int C, int r, void* stream);
+
+/* dst[b][p][dst_off + c] = src[(b % srcB)][p][src_off + c]: builds the channel concatenations of
+ * MainToGroupDistributor (group_modules.py:55-82) and torch.cat([g, h], 2) (modules.py:59,89). */
+int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* dst, int lddst, int B, int P, int C, void* stream);
+
+/* CBAM (model/cbam.py:21-77) on g [B][P=H*W][C] and the residual add of FeatureFusionBlock
+ * (modules.py:36-39): out = g + CBAM(g).  mlp weights as in the checkpoint: w1 [C/16][C], b1, w2 [C][C/16], b2;
+ * spatial 7x7 conv weight sw [2][7][7] (channel 0 = max, 1 = mean), bias sb[1].
+ * workspace: xmem_cbam_workspace_bytes(B, H*W, C). */
+size_t xmem_cbam_workspace_bytes(int B, int P, int C);
+int xmem_cbam_residual(const float* g, float* out, int B, int H, int W, int C,
+                       const float* w1, const float* b1, const float* w2, const float* b2,
+                       const float* sw, const float* sb, void* workspace, size_t workspace_bytes, void* stream);
+
+/* GRU-like gate shared by HiddenUpdater / HiddenReinforcer (modules.py:63-72, 93-99):
+ * values [B][P][3*Ch] = (forget | update | new), h [B][P][Ch] -> new_h [B][P][Ch] */
+int xmem_gru_gate(const float* values, const float* h, float* new_h, int B, int P, int Ch, void* stream);
+
+/* y = a + b + c elementwise (n floats), HiddenUpdater sum modules.py:56-57 */
+int xmem_add3(const float* a, const float* b, const float* c, float* y, size_t n, void* stream);
+
+/* image [3][H][W] (NCHW, unpadded) -> [Hp][Wp][4] NHWC, zero padded as pad_divide_by
+ * (util/tensor_util.py:47-61): left/top pads lw, lh; 4th channel zero. */
+int xmem_pack_image(const float* img, float* out, int H, int W, int Hp, int Wp, int lh, int lw, void* stream);
+
+/* value-encoder input, model/network.py:73-81 + modules.py:126-131: per object k the 5 channels
+ * (r,g,b,mask_k,sum_{j!=k} mask_j) padded to 8: image4 [Hp][Wp][4], masks [K][Hp][Wp] -> out [K][Hp][Wp][8] */
+int xmem_pack_value_input(const float* image4, const float* masks, float* out, int K, int Hp, int Wp, void* stream);
+
+/* KeyProjection activations, modules.py:207-211: proj [P][ldp] = (key C_k | d 1 | e C_k | pad) ->
+ * key [P][C_k], shrinkage [P] = d^2+1, selection [P][C_k] = sigmoid(e) */
+int xmem_key_post(const float* proj, int ldp, float* key, float* shrinkage, float* selection, int P, int Ck, void* stream);
+
+/* Decoder tail + segment(): model/modules.py:247-248 (x4 bilinear), network.py:111-115 (sigmoid),
+ * model/aggregate.py:6-17 (soft aggregation + softmax), util/tensor_util.py:63-77 (unpad).
+ * logits [K][h4][w4] -> prob [K+1][H][W] (NCHW, crop offsets lh, lw inside the padded 4*h4 x 4*w4 frame);
+ * prob_padded (nullable) receives the uncropped [K+1][4*h4][4*w4]. */
+int xmem_logits_to_prob(const float* logits, float* prob, float* prob_padded, int K, int h4, int w4,
+                        int H, int W, int lh, int lw, void* stream);
+
+/* aggregate() of given masks (inference_core.py:128,163): masks [K][H][W] -> prob [K+1][H][W] */
+int xmem_aggregate_masks(const float* masks, float* prob, int K, int H, int W, void* stream);
+
+/* Given-mask / prediction merge of InferenceCore.step (inference/inference_core.py:117-127):
+ * region = sum_k mask_k > 0.5; out_k = mask_k if bit k of valid_bits else (region ? 0 : pred_k).  [K][H][W] each. */
+int xmem_merge_masks(const float* pred_no_bg, const float* mask, uint64_t valid_bits, float* out, int K, int H, int W, void* stream);
+
+/* F.interpolate(prob, shape, mode='bilinear', align_corners=False) of _post_process (inference/run_on_video.py:166-168);
+ * in [C][Hi][Wi] -> out [C][Ho][Wo] */
+int xmem_resize_bilinear(const float* in, float* out, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* torch.argmax(prob, dim=0) -> uint8, inference/run_on_video.py:170-172; prob [C][H][W] */
+int xmem_argmax_u8(const float* prob, uint8_t* out, int C, int H, int W, void* stream);
+
+/* NHWC [B][P][C] (pixel stride ld) <-> NCHW [B][C][P] layout transposes for the Python surface */
+int xmem_nhwc_to_nchw(const float* in, int ld, float* out, int B, int P, int C, void* stream);
+int xmem_nchw_to_nhwc(const float* in, float* out, int ld, int B, int P, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Memory readout: fused anisotropic-L2 similarity + streaming top-k + softmax.
+ * Replaces get_similarity + do_softmax (model/memory_util.py:7-65) as called from
+ * MemoryManager.match_memory (inference/memory_manager.py:82-120,143-177) without ever
+ * materialising the N x HW matrix, and `_readout` (memory_manager.py:57-59,185-188).
+ * ------------------------------------------------------------------------------------------ */
+#define XMEM_MAX_SEGMENTS 4
+typedef struct {
+    const float* key;        /* [n][C_k] rows */
+    const float* shrinkage;  /* [n] or NULL (treated as 1, memory_util.py:36-37) */
+    int n;                   /* elements in this segment (may be 0) */
+} xmem_key_segment;
+
+/* segments are searched as one virtual concatenation (long | temporary | permanent in the reference's
+ * order, memory_manager.py:82-83); out indices are positions in that concatenation.
+ * qk [HW][C_k]; qe [HW][C_k] or NULL.  top_k in [1, 112], sum(n) >= top_k else XMEM_ERR_TOPK.
+ * out_w [HW][top_k] softmax weights exp(v)/sum exp(v) (no max shift, memory_util.py:48-49), sorted by
+ * descending similarity; out_idx [HW][top_k]; out_sim (nullable) [HW][top_k] raw similarities. */
+size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int top_k);
+int xmem_affinity_topk(const xmem_key_segment* segs_host, int n_seg,
+                       const float* qk, const float* qe, int Ck, int HW, int top_k,
+                       float* out_w, int32_t* out_idx, float* out_sim,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* usage = affinity.sum(dim=2) (memory_util.py:62-63) restricted to [first, first+count) of the index space,
+ * accumulated order-independently (64-bit fixed point) and then folded into the store counters as
+ * KeyValueMemoryStore.update_usage does (kv_memory_store.py:96-103): use_count += usage; life_count += 1.
+ * fx_scratch: count uint64, zeroed by the call. */
+int xmem_usage_update(const float* w, const int32_t* idx, int HW, int top_k, int first, int count,
+                      float* use_count, float* life_count, uint64_t* fx_scratch, void* stream);
+
+typedef struct {
+    const float* value;  /* [n][C_v] rows of ONE object */
+    int n;
+} xmem_value_segment;
+
+/* out[obj][q][c] = sum_s w[q][s] * V_obj[idx[q][s]][c]   (sparse form of v @ affinity).
+ * vsegs_host: n_obj * n_seg entries, object-major; all objects share the index space of the group.
+ * out [n_obj][HW][ldout] NHWC rows (pixel stride ldout >= C_v). */
+int xmem_readout_sparse(const xmem_value_segment* vsegs_host, int n_obj, int n_seg,
+                        const float* w, const int32_t* idx, int HW, int top_k, int Cv,
+                        float* out, int ldout, size_t obj_stride, void* stream);
+
+/* Dense similarity (no top-k): sim[n][p], n over one segment, p over P queries.  Used by the long-term
+ * consolidation (memory_manager.py:368) where the softmax runs over the candidate axis. out [P][n] (query-major). */
+int xmem_similarity_dense(const float* key, const float* shrinkage, int n,
+                          const float* qk, const float* qe, int P, int Ck, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Long-term consolidation (memory_manager.py:349-390) and eviction (kv_memory_store.py:160-181).
+ * ------------------------------------------------------------------------------------------ */
+/* usage[i] = use[i] / life[i] (kv_memory_store.py:183-189) */
+int xmem_usage_ratio(const float* use, const float* life, float* usage, int n, void* stream);
+
+/* torch.topk(values, k, largest, sorted=True) over a 1-D array by exact ranking (ties -> lower index first).
+ * out_idx [k], out_val [k]. */
+int xmem_topk_1d(const float* values, int n, int k, int largest, int32_t* out_idx, float* out_val, void* stream);
+
+/* dst[i][0:C] = src[index[i]][0:C], i < n  (prototype gather, memory_manager.py:362-363) */
+int xmem_gather_rows(const float* src, int C, const int32_t* index, int n, float* dst, void* stream);
+
+/* in-place softmax over the last `count` entries of each row of sim [P][n] (do_softmax with top_k=None on
+ * similarity[:, -count:], memory_util.py:55-60); entries before are zeroed. */
+int xmem_softmax_rows_suffix(float* sim, int P, int n, int count, void* stream);
+
+/* out[p][c] = sum_i aff[p][n - count + i] * V[i][c], i < count: prototype values / shrinkage
+ * (memory_manager.py:382-388).  V [count][C]. out [P][C]. */
+int xmem_weighted_rows(const float* aff, int P, int n, int count, const float* V, int C, float* out, void* stream);
+
+/* stream compaction for remove_obsolete_features: keep[i] = usage[i] > threshold (kv_memory_store.py:165);
+ * out_index receives the kept indices in order, *out_count (device int) their number. */
+int xmem_select_greater(const float* usage, int n, const float* threshold_dev, int32_t* out_index, int32_t* out_count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMEM_HIP_H */

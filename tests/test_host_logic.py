@@ -1,0 +1,138 @@
+"""CPU suite: host-side logic and the C-ABI surface (no kernel is launched)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_state_dict_spec_matches_reference_names(synth_sd):
+    from xmem2_amd.arch import state_dict_spec, infer_dims
+    spec = state_dict_spec()
+    assert len(spec) == 412
+    assert list(spec.keys()) == list(synth_sd.keys())
+    n_params = sum(int(np.prod(s)) for k, s in spec.items() if not k.endswith('num_batches_tracked'))
+    assert n_params + 58 == 62220354          # 58 BatchNorm counters; total printed by the reference's state_dict
+    assert infer_dims(synth_sd) == (64, 512, 64)
+
+
+def test_synthetic_weights_are_reproducible():
+    from xmem2_amd.synth import hash_normal, hash_uniform
+    a = hash_normal(8, 12345)
+    np.testing.assert_array_equal(a, hash_normal(8, 12345))
+    assert abs(float(hash_normal(200000, 7).std()) - 1.0) < 0.01
+    u = hash_uniform(1000, 3, 2.0, 3.0)
+    assert u.min() >= 2.0 and u.max() < 3.0
+
+
+def test_pad_amounts_match_reference_padding():
+    from xmem2_amd.tensor_util import pad_amounts, pad_divide_by, unpad
+    from oracle import cpu_ref as R
+    for h, w in [(480, 854), (240, 427), (50, 70), (96, 128), (1080, 1920), (17, 33)]:
+        x = torch.zeros(3, h, w)
+        _, pad = R.pad_divide_by(x, 16)
+        assert pad_amounts(h, w, 16) == tuple(pad)
+    g = load_golden('misc')
+    p, pad = pad_divide_by(torch.from_numpy(g['pad_in']), 16)
+    np.testing.assert_array_equal(p.numpy(), g['pad_out'])
+    np.testing.assert_array_equal(unpad(p, pad).numpy(), g['pad_in'])
+
+
+def test_mask_mapper_matches_golden():
+    from xmem2_amd.mask_mapper import MaskMapper
+    g = load_golden('misc')
+    m = MaskMapper()
+    a1, l1 = m.convert_mask(g['mask_in'], exhaustive=True)
+    np.testing.assert_array_equal(a1.numpy(), g['onehot1']); assert list(l1) == list(g['labels1'])
+    a2, l2 = m.convert_mask(g['mask_in2'], exhaustive=True)
+    np.testing.assert_array_equal(a2.numpy(), g['onehot2']); assert list(l2) == list(g['labels2'])
+    assert list(m.remappings.values()) == list(g['remap_vals'])
+    np.testing.assert_array_equal(m.remap_index_mask(g['remap_in']), g['remap_out'])
+    with pytest.raises(AssertionError):
+        MaskMapper().convert_mask(g['mask_in'], exhaustive=False) and m.convert_mask(g['mask_in'], exhaustive=False)
+
+
+def test_iou_definition():
+    from xmem2_amd.tensor_util import compute_array_iou
+    g = load_golden('misc')
+    assert abs(compute_array_iou(g['iou_seg'], g['iou_gt']) - float(g['iou'])) < 1e-7
+    z = np.zeros((4, 4), np.uint8)
+    assert compute_array_iou(z, z) == pytest.approx(1.0)
+
+
+def test_config_keys_match_reference_defaults():
+    from xmem2_amd.configuration import VIDEO_INFERENCE_CONFIG as C
+    assert C['mem_every'] == 10 and C['top_k'] == 30 and C['max_mid_term_frames'] == 10 and C['min_mid_term_frames'] == 5
+    assert C['num_prototypes'] == 128 and C['max_long_term_elements'] == 10000 and C['deep_update_every'] == -1
+    assert C['enable_long_term'] is True and C['key_dim'] == 64 and C['value_dim'] == 512 and C['hidden_dim'] == 64
+    assert set(C) >= {'size', 'model', 'save_masks', 'masks_out_path', 'enable_long_term_count_usage'}
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'xmem_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(xmem_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from xmem2_amd import _lib
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/xmem_hip.h but not exported'
+    assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
+    assert lib.xmem_version() == 1
+    assert b'top_k' in lib.xmem_last_error_string(-5)
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    from xmem2_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()                       # all-zero descriptor: null pointers
+    assert lib.xmem_conv2d_nhwc(ctypes.byref(d), None, 0, None) == -1
+    assert lib.xmem_conv2d_workspace_bytes(ctypes.byref(d)) == 0
+    assert lib.xmem_maxpool3x3s2(None, None, 1, 8, 8, 64, None) == -1
+    assert lib.xmem_affinity_topk(None, 1, None, None, 64, 10, 30, None, None, None, None, 0, None) == -1
+    assert lib.xmem_topk_1d(None, 10, 3, 1, None, None, None) == -1
+    assert lib.xmem_affinity_topk_workspace_bytes(51840, 1620, 30) > 0
+
+
+def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
+    from xmem2_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'missing.so'))
+    with pytest.raises(_lib.XMemHipError):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    from xmem2_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.aggregate_masks(torch.zeros(1, 16, 16))
+
+
+def test_arena_store_bookkeeping_on_cpu():
+    """The arena store's group / sieve bookkeeping is plain tensor plumbing and can be checked without kernels."""
+    from xmem2_amd.kv_memory_store import KeyValueMemoryStore
+    st = KeyValueMemoryStore(count_usage=True)
+    hw, ck, cv = 6, 8, 4
+    mk = lambda n, c, base: torch.arange(n * c, dtype=torch.float32).view(n, c) + base
+    for f in range(3):
+        pos = st.add(mk(hw, ck, 100 * f), mk(hw, cv, 100 * f).unsqueeze(0), torch.full((hw,), float(f)), mk(hw, ck, 7), [1])
+        # the reference's float floor-division with a 1e-9 fudge (kv_memory_store.py:92) yields 0, 0, 1, ... - kept as is
+        assert pos == max(0, f - 1)
+    st.add(mk(hw, ck, 300), torch.stack([mk(hw, cv, 300), mk(hw, cv, 900)]), torch.full((hw,), 3.0), mk(hw, ck, 7), [1, 2])
+    assert st.size == 4 * hw and st.num_groups == 2 and st.get_v_size(0) == 4 * hw and st.get_v_size(1) == hw
+    assert st.key.shape == (1, ck, 4 * hw) and st.value[0].shape == (1, cv, 4 * hw) and st.shrinkage.shape == (1, 1, 4 * hw)
+    st.sieve_by_range(0, -2 * hw, min_size=2 * hw + hw)      # consolidation-style: keep the last 2 frames
+    assert st.size == 2 * hw and st.get_v_size(0) == 2 * hw and st.get_v_size(1) == hw
+    assert float(st.key_rows()[0, 0]) == 200.0 and float(st.shrinkage_rows()[0]) == 2.0
+    st.remove_at(0, hw)
+    assert st.size == hw and float(st.key_rows()[0, 0]) == 300.0
+    with pytest.raises(AssertionError):
+        KeyValueMemoryStore(False).add(mk(hw, ck, 0), torch.zeros(2, hw, cv), None, None, [2, 1])

@@ -1,0 +1,309 @@
+// Implicit-GEMM convolution on the CDNA4 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view:  M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin (Cin fastest).
+// NHWC activations and [Cout][KH][KW][Cin] weights make both operands K-contiguous, so one
+// 128-byte global segment feeds one padded LDS row and every MFMA operand fragment is a single
+// ds_read_b128 (row stride 36 floats -> the 16 lanes of a b128 lane-group hit 16 distinct 16-B slots).
+//
+// MFMA lane maps (cdna_hip_programming.md section 3): A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+// D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].  A lane reads 4 consecutive k (float4) at k-offset 4*(l>>5)
+// inside an 8-wide group; MFMA step j then contracts k = {j, 4+j} of the group - the same permutation for
+// A and B, so the sum is unchanged.  fp32-input MFMA is an exact fmaf chain: results are fp32-roundoff
+// class against the reference's CPU convolution.
+//
+// Replaces the nn.Conv2d/BatchNorm2d/ReLU/residual call sites listed in include/xmem_hip.h.
+#include "common.hpp"
+
+#define BK 32
+#define LDK 36
+
+struct ConvArgs {
+    const float* in; const float* w; const float* scale; const float* shift; const float* res;
+    float* out; float* partial;
+    int B, H, W, Cin, ldin;
+    int Ho, Wo, Cout, ldout, ldres;
+    int KH, KW, stride, pad;
+    int K, M, HoWo;
+    int relu_in, relu_out;
+    int nk, splitk, kt_per_split;
+    int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int TM, int TN, bool GENERIC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+    constexpr int WN = BN / (32 * TN);
+    constexpr int WM = BM / (32 * TM);
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int BUF = (BM + BN) * LDK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lrow = tid >> 3, c4 = tid & 7;
+
+    // XCD-aware tile order: consecutive tile ids (same M-tile, neighbouring N-tiles) stay on one XCD / L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int a_ih0[RA], a_iw0[RA], a_pix[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int b = m / p.HoWo, rem = m - b * p.HoWo;
+            const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
+            a_pix[i] = b * p.H * p.W;
+        } else {
+            a_ih0[i] = -(1 << 28); a_iw0[i] = -(1 << 28); a_pix[i] = 0;
+        }
+    }
+
+    const int kt_begin = blockIdx.z * p.kt_per_split;
+    const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
+
+    f32x4 ra[RA], rb[RB];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (!GENERIC) {
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const long off = (long)(a_pix[i] + ih * p.W + iw) * p.ldin + c0 + c4 * 4;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.in + off) : zero;
+            }
+        } else {
+            const int k = k0 + c4 * 4;
+            const bool kok = k < p.K;
+            const int tap = k / p.Cin, c0 = k - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                const bool ok = kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const long off = (long)(a_pix[i] + ih * p.W + iw) * p.ldin + c0;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.in + off) : zero;
+            }
+        }
+        if (p.relu_in) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
+                ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+            }
+        }
+        const int kb = k0 + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + lrow + 32 * i;
+            const bool ok = n < p.Cout && kb < p.K;
+            rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + kb) : zero;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * BUF;
+        float* Bs = As + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDK + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDK + c4 * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        const bool has_next = kt + 1 < kt_end;
+        if (has_next) load_tile(kt + 1);           // global loads in flight under the MFMAs below
+
+        const float* As = smem + buf * BUF + (wm * 32 * TM + l31) * LDK + lh * 4;
+        const float* Bs = smem + buf * BUF + BM * LDK + (wn * 32 * TN + l31) * LDK + lh * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane owns output channel n (col) and 16 pixels (rows) per 32x32 tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + l31;
+        if (n >= p.Cout) continue;
+        float sc = 1.f, sh = 0.f;
+        if (p.splitk == 1) { sc = p.scale[n]; sh = p.shift[n]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.splitk == 1) {
+                    v = v * sc + sh;
+                    if (p.res) v += p.res[(size_t)m * p.ldres + n];
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    p.out[(size_t)m * p.ldout + n] = v;
+                } else {
+                    p.partial[((size_t)blockIdx.z * p.M + m) * p.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void conv_splitk_reduce_kernel(ConvArgs p) {
+    const size_t total = (size_t)p.M * p.Cout;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(e / p.Cout), n = (int)(e - (size_t)m * p.Cout);
+        float v = 0.f;
+        for (int z = 0; z < p.splitk; ++z) v += p.partial[(size_t)z * total + e];
+        v = v * p.scale[n] + p.shift[n];
+        if (p.res) v += p.res[(size_t)m * p.ldres + n];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        p.out[(size_t)m * p.ldout + n] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------
+namespace {
+
+struct Plan { int bm, bn, splitk, kt_per_split, nk; bool generic; };
+
+int validate(const xmem_conv_desc* d) {
+    if (!d || !d->in || !d->w || !d->scale || !d->shift || !d->out) return XMEM_ERR_BAD_ARG;
+    if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
+        d->stride <= 0 || d->pad < 0) return XMEM_ERR_BAD_ARG;
+    if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
+    if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
+    if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
+    return XMEM_OK;
+}
+
+inline void out_dims(const xmem_conv_desc* d, int& Ho, int& Wo) {
+    Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+}
+
+Plan make_plan(const xmem_conv_desc* d) {
+    int Ho, Wo; out_dims(d, Ho, Wo);
+    const int M = d->B * Ho * Wo, K = d->KH * d->KW * d->Cin;
+    Plan pl;
+    pl.generic = (d->Cin % BK) != 0;
+    pl.nk = cdiv(K, BK);
+    auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
+    // 256 CUs; two resident workgroups per CU is the sweet spot for the 128-wide tiles
+    if (d->Cout > 64 && tiles(128, 128) >= 384) { pl.bm = 128; pl.bn = 128; }
+    else if (tiles(128, 64) >= 384) { pl.bm = 128; pl.bn = 64; }
+    else { pl.bm = 64; pl.bn = 64; }
+    pl.splitk = 1;
+    const long t = tiles(pl.bm, pl.bn);
+    if (t < 384) {
+        int want = (int)cdiv(512, (int)t);
+        int maxs = pl.nk / 8; if (maxs < 1) maxs = 1;
+        pl.splitk = want < maxs ? want : maxs;
+        if (pl.splitk > 16) pl.splitk = 16;
+        if (pl.splitk < 1) pl.splitk = 1;
+    }
+    pl.kt_per_split = cdiv(pl.nk, pl.splitk);
+    pl.splitk = cdiv(pl.nk, pl.kt_per_split);
+    return pl;
+}
+
+template <int BM, int BN, int TM, int TN, bool G>
+int launch_cfg(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
+    auto kern = conv_mfma_kernel<BM, BN, TM, TN, G>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return xmem_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
+    if (validate(d) != XMEM_OK) return 0;
+    Plan pl = make_plan(d);
+    if (pl.splitk == 1) return 0;
+    int Ho, Wo; out_dims(d, Ho, Wo);
+    return (size_t)pl.splitk * d->B * Ho * Wo * d->Cout * sizeof(float);
+}
+
+extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = validate(d);
+    if (rc != XMEM_OK) return rc;
+    Plan pl = make_plan(d);
+    int Ho, Wo; out_dims(d, Ho, Wo);
+    ConvArgs a;
+    a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.out = d->out;
+    a.partial = reinterpret_cast<float*>(workspace);
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldin = d->ldin;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout; a.ldout = d->ldout; a.ldres = d->ldres;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.K = d->KH * d->KW * d->Cin; a.M = d->B * Ho * Wo; a.HoWo = Ho * Wo;
+    a.relu_in = d->relu_in; a.relu_out = d->relu_out;
+    a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
+    a.tiles_m = cdiv(a.M, pl.bm); a.tiles_n = cdiv(a.Cout, pl.bn);
+    if (pl.splitk > 1) {
+        const size_t need = (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
+        if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (pl.bm == 128 && pl.bn == 128)
+        rc = pl.generic ? launch_cfg<128, 128, 2, 2, true>(a, s) : launch_cfg<128, 128, 2, 2, false>(a, s);
+    else if (pl.bm == 128 && pl.bn == 64)
+        rc = pl.generic ? launch_cfg<128, 64, 2, 1, true>(a, s) : launch_cfg<128, 64, 2, 1, false>(a, s);
+    else
+        rc = pl.generic ? launch_cfg<64, 64, 1, 1, true>(a, s) : launch_cfg<64, 64, 1, 1, false>(a, s);
+    if (rc != XMEM_OK) return rc;
+    if (pl.splitk > 1) {
+        const size_t total = (size_t)a.M * a.Cout;
+        int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+        rc = xmem_check_launch();
+    }
+    return rc;
+}

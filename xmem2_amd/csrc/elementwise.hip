@@ -1,0 +1,587 @@
+// HBM-bound kernels of the encoders / decoder: pooling, resampling, CBAM, gates, layout packing,
+// soft aggregation and argmax.  All NHWC fp32, float4-vectorised over channels (C % 4 == 0), coalesced:
+// consecutive lanes walk consecutive channels of one pixel.  Reference call sites: include/xmem_hip.h.
+#include "common.hpp"
+#include <math.h>
+
+namespace {
+inline int grid_for(size_t n, int block = 256, int cap = 8192) {
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > (size_t)cap ? cap : g);
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// max pool 3x3 / stride 2 / pad 1  (implicit -inf padding like nn.MaxPool2d)
+// ---------------------------------------------------------------------------------------------
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                    int B, int H, int W, int C, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t pix = e / C4;
+        const int ow = (int)(pix % Wo); pix /= Wo;
+        const int oh = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ih = oh * 2 - 1 + dy;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iw = ow * 2 - 1 + dx;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oh) * Wo + ow) * C + c4 * 4) = m;
+    }
+}
+
+extern "C" int xmem_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return XMEM_ERR_BAD_ARG;
+    if (C % 4) return XMEM_ERR_UNSUPPORTED;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C, Ho, Wo);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear x2 (align_corners=False) + broadcast skip add
+// source index as ATen's area_pixel_compute_source_index: src = 0.5*(dst+0.5)-0.5, clamped at 0
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int size, int& i0, int& i1, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > size - 1) i0 = size - 1;
+    i1 = i0 + (i0 < size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ void upsample2x_add_kernel(const float* __restrict__ g, const float* __restrict__ skip,
+                                      float* __restrict__ out, int B, int h, int w, int C) {
+    const int C4 = C >> 2, H = 2 * h, W = 2 * w;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t pix = e / C4;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        int y0, y1, x0, x1; float ly, lx;
+        bilinear_src(y, 0.5f, h, y0, y1, ly);
+        bilinear_src(x, 0.5f, w, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* gb = g + (size_t)b * h * w * C + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y0 * w + x0) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y0 * w + x1) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y1 * w + x0) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y1 * w + x1) * C);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(skip + ((size_t)y * W + x) * C + c4 * 4);
+        f32x4 o;
+        o.x = s.x + (hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x));
+        o.y = s.y + (hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y));
+        o.z = s.z + (hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z));
+        o.w = s.w + (hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w));
+        *reinterpret_cast<f32x4*>(out + (((size_t)b * H + y) * W + x) * C + c4 * 4) = o;
+    }
+}
+
+extern "C" int xmem_upsample2x_add(const float* g, const float* skip, float* out, int B, int h, int w, int C, void* stream) {
+    if (!g || !skip || !out || B <= 0 || h <= 0 || w <= 0 || C <= 0) return XMEM_ERR_BAD_ARG;
+    if (C % 4) return XMEM_ERR_UNSUPPORTED;
+    const size_t total = (size_t)B * 4 * h * w * (C / 4);
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, skip, out, B, h, w, C);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// area (average) downsample by integer ratio
+// ---------------------------------------------------------------------------------------------
+__global__ void area_down_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out, int ldout,
+                                 int B, int H, int W, int C, int r) {
+    const int Ho = H / r, Wo = W / r;
+    const size_t total = (size_t)B * Ho * Wo * C;
+    const float inv = 1.0f / (float)(r * r);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        size_t pix = e / C;
+        const int ow = (int)(pix % Wo); pix /= Wo;
+        const int oh = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float s = 0.f;
+        for (int dy = 0; dy < r; ++dy)
+            for (int dx = 0; dx < r; ++dx)
+                s += in[(((size_t)b * H + oh * r + dy) * W + ow * r + dx) * ldin + c];
+        out[(((size_t)b * Ho + oh) * Wo + ow) * ldout + c] = s * inv;
+    }
+}
+
+extern "C" int xmem_area_downsample(const float* in, int ldin, float* out, int ldout, int B, int H, int W, int C, int r, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0) return XMEM_ERR_BAD_ARG;
+    if (H % r || W % r) return XMEM_ERR_UNSUPPORTED;
+    const size_t total = (size_t)B * (H / r) * (W / r) * C;
+    hipLaunchKernelGGL(area_down_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, B, H, W, C, r);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel-slice copy with object broadcast (concat builder)
+// ---------------------------------------------------------------------------------------------
+__global__ void copy_channels_kernel(const float* __restrict__ src, int ldsrc, int srcB, float* __restrict__ dst, int lddst,
+                                     int B, int P, int C4) {
+    const size_t total = (size_t)B * P * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t r = e / C4;
+        const int pidx = (int)(r % P);
+        const int b = (int)(r / P);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(b % srcB) * P + pidx) * ldsrc + c4 * 4);
+        *reinterpret_cast<f32x4*>(dst + ((size_t)b * P + pidx) * lddst + c4 * 4) = v;
+    }
+}
+
+extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* dst, int lddst, int B, int P, int C, void* stream) {
+    if (!src || !dst || B <= 0 || P <= 0 || C <= 0 || srcB <= 0) return XMEM_ERR_BAD_ARG;
+    if (C % 4 || ldsrc % 4 || lddst % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return XMEM_ERR_UNSUPPORTED;
+    const size_t total = (size_t)B * P * (C / 4);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, ldsrc, srcB, dst, lddst, B, P, C / 4);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// CBAM + residual:  out = g + SpatialGate(ChannelGate(g))
+//   1. channel_pool:   avg / max over the P pixels per (b, c)            -> pooled [B][2][C]
+//   2. channel_mlp:    sigmoid(mlp(avg) + mlp(max))                        -> cscale [B][C]
+//   3. compress:       per pixel max / mean over c of g*cscale             -> comp [B][P][2]
+//   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg
+// ---------------------------------------------------------------------------------------------
+__global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __restrict__ pooled, int P, int C) {
+    // block = 256 threads = 64 channels x 4 pixel stripes; grid = (C/64, B)
+    __shared__ float ssum[4][64];
+    __shared__ float smax[4][64];
+    const int cl = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    float s = 0.f, m = -INFINITY;
+    if (c < C) {
+        const float* gb = g + (size_t)b * P * C + c;
+        for (int pidx = stripe; pidx < P; pidx += 4) {
+            const float v = gb[(size_t)pidx * C];
+            s += v; m = fmaxf(m, v);
+        }
+    }
+    ssum[stripe][cl] = s; smax[stripe][cl] = m;
+    __syncthreads();
+    if (stripe == 0 && c < C) {
+        const float ts = (ssum[0][cl] + ssum[1][cl]) + (ssum[2][cl] + ssum[3][cl]);
+        const float tm = fmaxf(fmaxf(smax[0][cl], smax[1][cl]), fmaxf(smax[2][cl], smax[3][cl]));
+        pooled[((size_t)b * 2 + 0) * C + c] = ts / (float)P;
+        pooled[((size_t)b * 2 + 1) * C + c] = tm;
+    }
+}
+
+__global__ void cbam_channel_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
+                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                        float* __restrict__ cscale, int C, int Cr) {
+    // one block per b; hidden [2][Cr] in LDS
+    extern __shared__ float hid[];
+    const int b = blockIdx.x;
+    const float* pb = pooled + (size_t)b * 2 * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int o = wave; o < 2 * Cr; o += nw) {
+        const int which = o / Cr, j = o - which * Cr;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += pb[which * C + c] * w1[(size_t)j * C + c];
+        s = wave_sum(s);
+        if (lane == 0) hid[o] = fmaxf(s + b1[j], 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float sa = 0.f, sm = 0.f;
+        for (int j = 0; j < Cr; ++j) {
+            const float w = w2[(size_t)c * Cr + j];
+            sa += hid[j] * w; sm += hid[Cr + j] * w;
+        }
+        const float att = (sa + b2[c]) + (sm + b2[c]);
+        cscale[(size_t)b * C + c] = sigmoidf_(att);
+    }
+}
+
+__global__ void cbam_compress_kernel(const float* __restrict__ g, const float* __restrict__ cscale, float* __restrict__ comp,
+                                     int BP, int P, int C) {
+    // one wave per pixel
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int pix = blockIdx.x * wpb + (threadIdx.x >> 6); pix < BP; pix += gridDim.x * wpb) {
+        const int b = pix / P;
+        const float* gp = g + (size_t)pix * C;
+        const float* cs = cscale + (size_t)b * C;
+        float s = 0.f, m = -INFINITY;
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
+            const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c);
+            const float a0 = v.x * k.x, a1 = v.y * k.y, a2 = v.z * k.z, a3 = v.w * k.w;
+            s += (a0 + a1) + (a2 + a3);
+            m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+        }
+        s = wave_sum(s); m = wave_max(m);
+        if (lane == 0) { comp[(size_t)pix * 2 + 0] = m; comp[(size_t)pix * 2 + 1] = s / (float)C; }
+    }
+}
+
+__global__ void cbam_spatial_gate_kernel(const float* __restrict__ comp, const float* __restrict__ sw, const float* __restrict__ sb,
+                                         float* __restrict__ sgate, int B, int H, int W) {
+    const int total = B * H * W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int x = e % W, y = (e / W) % H, b = e / (W * H);
+        float s = sb[0];
+        for (int ch = 0; ch < 2; ++ch)
+            for (int dy = 0; dy < 7; ++dy) {
+                const int iy = y + dy - 3;
+                if ((unsigned)iy >= (unsigned)H) continue;
+                for (int dx = 0; dx < 7; ++dx) {
+                    const int ix = x + dx - 3;
+                    if ((unsigned)ix >= (unsigned)W) continue;
+                    s += comp[(((size_t)b * H + iy) * W + ix) * 2 + ch] * sw[(ch * 7 + dy) * 7 + dx];
+                }
+            }
+        sgate[e] = sigmoidf_(s);
+    }
+}
+
+__global__ void cbam_apply_kernel(const float* __restrict__ g, const float* __restrict__ cscale, const float* __restrict__ sgate,
+                                  float* __restrict__ out, int BP, int P, int C4) {
+    const size_t total = (size_t)BP * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        const int pix = (int)(e / C4);
+        const int b = pix / P;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)pix * C4 * 4 + c4 * 4);
+        const f32x4 k = *reinterpret_cast<const f32x4*>(cscale + (size_t)b * C4 * 4 + c4 * 4);
+        const float sg = sgate[pix];
+        f32x4 o;
+        o.x = v.x + (v.x * k.x) * sg; o.y = v.y + (v.y * k.y) * sg;
+        o.z = v.z + (v.z * k.z) * sg; o.w = v.w + (v.w * k.w) * sg;
+        *reinterpret_cast<f32x4*>(out + (size_t)pix * C4 * 4 + c4 * 4) = o;
+    }
+}
+
+extern "C" size_t xmem_cbam_workspace_bytes(int B, int P, int C) {
+    if (B <= 0 || P <= 0 || C <= 0) return 0;
+    return align_up((size_t)B * 2 * C * 4, 256) + align_up((size_t)B * C * 4, 256) +
+           align_up((size_t)B * P * 2 * 4, 256) + align_up((size_t)B * P * 4, 256);
+}
+
+extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int W, int C,
+                                  const float* w1, const float* b1, const float* w2, const float* b2,
+                                  const float* sw, const float* sb, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !out || !w1 || !b1 || !w2 || !b2 || !sw || !sb || B <= 0 || H <= 0 || W <= 0 || C <= 0) return XMEM_ERR_BAD_ARG;
+    if (C % 16) return XMEM_ERR_UNSUPPORTED;
+    const int P = H * W, Cr = C / 16;
+    if (!workspace || workspace_bytes < xmem_cbam_workspace_bytes(B, P, C)) return XMEM_ERR_WORKSPACE;
+    char* ws = (char*)workspace;
+    float* pooled = (float*)ws; ws += align_up((size_t)B * 2 * C * 4, 256);
+    float* cscale = (float*)ws; ws += align_up((size_t)B * C * 4, 256);
+    float* comp = (float*)ws;   ws += align_up((size_t)B * P * 2 * 4, 256);
+    float* sgate = (float*)ws;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, s, g, pooled, P, C);
+    hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(256), 2 * Cr * sizeof(float), s, pooled, w1, b1, w2, b2, cscale, C, Cr);
+    hipLaunchKernelGGL(cbam_compress_kernel, dim3(grid_for((size_t)B * P, 4)), dim3(256), 0, s, g, cscale, comp, B * P, P, C);
+    hipLaunchKernelGGL(cbam_spatial_gate_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, s, comp, sw, sb, sgate, B, H, W);
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3(grid_for((size_t)B * P * (C / 4))), dim3(256), 0, s, g, cscale, sgate, out, B * P, P, C / 4);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU-like gate, add3
+// ---------------------------------------------------------------------------------------------
+__global__ void gru_gate_kernel(const float* __restrict__ values, const float* __restrict__ h, float* __restrict__ nh,
+                                size_t BP, int Ch) {
+    const size_t total = BP * Ch;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = e / Ch; const int c = (int)(e - pix * Ch);
+        const float* v = values + pix * 3 * Ch;
+        const float f = sigmoidf_(v[c]), u = sigmoidf_(v[Ch + c]), n = tanhf(v[2 * Ch + c]);
+        nh[e] = f * h[e] * (1.f - u) + u * n;
+    }
+}
+
+extern "C" int xmem_gru_gate(const float* values, const float* h, float* new_h, int B, int P, int Ch, void* stream) {
+    if (!values || !h || !new_h || B <= 0 || P <= 0 || Ch <= 0) return XMEM_ERR_BAD_ARG;
+    const size_t BP = (size_t)B * P;
+    hipLaunchKernelGGL(gru_gate_kernel, dim3(grid_for(BP * Ch)), dim3(256), 0, (hipStream_t)stream, values, h, new_h, BP, Ch);
+    return xmem_check_launch();
+}
+
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                            float* __restrict__ y, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        y[e] = a[e] + b[e] + c[e];
+}
+
+extern "C" int xmem_add3(const float* a, const float* b, const float* c, float* y, size_t n, void* stream) {
+    if (!a || !b || !c || !y || n == 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add3_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, c, y, n);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// input packing
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_image_kernel(const float* __restrict__ img, float* __restrict__ out, int H, int W, int Hp, int Wp, int lh, int lw) {
+    const int total = Hp * Wp;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int x = e % Wp, y = e / Wp;
+        const int sy = y - lh, sx = x - lw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+            const size_t o = (size_t)sy * W + sx, plane = (size_t)H * W;
+            v.x = img[o]; v.y = img[plane + o]; v.z = img[2 * plane + o];
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)e * 4) = v;
+    }
+}
+
+extern "C" int xmem_pack_image(const float* img, float* out, int H, int W, int Hp, int Wp, int lh, int lw, void* stream) {
+    if (!img || !out || H <= 0 || W <= 0 || Hp < H || Wp < W || lh < 0 || lw < 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_image_kernel, dim3(grid_for((size_t)Hp * Wp)), dim3(256), 0, (hipStream_t)stream, img, out, H, W, Hp, Wp, lh, lw);
+    return xmem_check_launch();
+}
+
+__global__ void pack_value_input_kernel(const float* __restrict__ image4, const float* __restrict__ masks, float* __restrict__ out,
+                                        int K, int P) {
+    const size_t total = (size_t)K * P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(e % P), k = (int)(e / P);
+        const f32x4 im = *reinterpret_cast<const f32x4*>(image4 + (size_t)pix * 4);
+        float others = 0.f;
+        for (int j = 0; j < K; ++j) if (j != k) others += masks[(size_t)j * P + pix];
+        f32x4 lo = {im.x, im.y, im.z, masks[(size_t)k * P + pix]};
+        f32x4 hi = {others, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(out + e * 8) = lo;
+        *reinterpret_cast<f32x4*>(out + e * 8 + 4) = hi;
+    }
+}
+
+extern "C" int xmem_pack_value_input(const float* image4, const float* masks, float* out, int K, int Hp, int Wp, void* stream) {
+    if (!image4 || !masks || !out || K <= 0 || Hp <= 0 || Wp <= 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_value_input_kernel, dim3(grid_for((size_t)K * Hp * Wp)), dim3(256), 0, (hipStream_t)stream,
+                       image4, masks, out, K, Hp * Wp);
+    return xmem_check_launch();
+}
+
+__global__ void key_post_kernel(const float* __restrict__ proj, int ldp, float* __restrict__ key, float* __restrict__ shr,
+                                float* __restrict__ sel, int P, int Ck) {
+    const int per = 2 * Ck + 1;
+    const size_t total = (size_t)P * per;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(e / per), c = (int)(e - (size_t)pix * per);
+        const float v = proj[(size_t)pix * ldp + c];
+        if (c < Ck) key[(size_t)pix * Ck + c] = v;
+        else if (c == Ck) { if (shr) shr[pix] = v * v + 1.f; }
+        else if (sel) sel[(size_t)pix * Ck + (c - Ck - 1)] = sigmoidf_(v);
+    }
+}
+
+extern "C" int xmem_key_post(const float* proj, int ldp, float* key, float* shrinkage, float* selection, int P, int Ck, void* stream) {
+    if (!proj || !key || P <= 0 || Ck <= 0 || ldp < 2 * Ck + 1) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(key_post_kernel, dim3(grid_for((size_t)P * (2 * Ck + 1))), dim3(256), 0, (hipStream_t)stream,
+                       proj, ldp, key, shrinkage, selection, P, Ck);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder tail: x4 bilinear -> sigmoid -> soft aggregation -> softmax (-> crop)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float agg_logit(float p) {
+    p = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+    return logf(p / (1.f - p));
+}
+
+__device__ __forceinline__ float bilinear4(const float* lg, int h4, int w4, int y0, int y1, int x0, int x1, float ly, float lx) {
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * lg[(size_t)y0 * w4 + x0] + lx * lg[(size_t)y0 * w4 + x1]) +
+           ly * (hx * lg[(size_t)y1 * w4 + x0] + lx * lg[(size_t)y1 * w4 + x1]);
+}
+
+__global__ void logits_to_prob_kernel(const float* __restrict__ logits, float* __restrict__ prob, float* __restrict__ prob_pad,
+                                      int K, int h4, int w4, int H, int W, int lh, int lw) {
+    const int Hp = 4 * h4, Wp = 4 * w4;
+    const int total = Hp * Wp;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int x = e % Wp, y = e / Wp;
+        int y0, y1, x0, x1; float ly, lx;
+        bilinear_src(y, 0.25f, h4, y0, y1, ly);
+        bilinear_src(x, 0.25f, w4, x0, x1, lx);
+        // pass 1: background product and max logit
+        float bgp = 1.f, mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float pk = sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx));
+            bgp *= (1.f - pk);
+            mx = fmaxf(mx, agg_logit(pk));
+        }
+        const float l0 = agg_logit(bgp);
+        mx = fmaxf(mx, l0);
+        // pass 2: softmax denominator
+        float den = expf(l0 - mx);
+        for (int k = 0; k < K; ++k) {
+            const float pk = sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx));
+            den += expf(agg_logit(pk) - mx);
+        }
+        const int oy = y - lh, ox = x - lw;
+        const bool inside = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+        // pass 3: write
+        for (int k = -1; k < K; ++k) {
+            float l = l0;
+            if (k >= 0) l = agg_logit(sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx)));
+            const float pr = expf(l - mx) / den;
+            if (inside) prob[((size_t)(k + 1) * H + oy) * W + ox] = pr;
+            if (prob_pad) prob_pad[(size_t)(k + 1) * total + e] = pr;
+        }
+    }
+}
+
+extern "C" int xmem_logits_to_prob(const float* logits, float* prob, float* prob_padded, int K, int h4, int w4,
+                                   int H, int W, int lh, int lw, void* stream) {
+    if (!logits || !prob || K <= 0 || h4 <= 0 || w4 <= 0 || H <= 0 || W <= 0 || lh < 0 || lw < 0) return XMEM_ERR_BAD_ARG;
+    if (lh + H > 4 * h4 || lw + W > 4 * w4) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(logits_to_prob_kernel, dim3(grid_for((size_t)16 * h4 * w4)), dim3(256), 0, (hipStream_t)stream,
+                       logits, prob, prob_padded, K, h4, w4, H, W, lh, lw);
+    return xmem_check_launch();
+}
+
+__global__ void aggregate_masks_kernel(const float* __restrict__ masks, float* __restrict__ prob, int K, int P) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P; e += gridDim.x * blockDim.x) {
+        float bgp = 1.f, mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            const float pk = masks[(size_t)k * P + e];
+            bgp *= (1.f - pk);
+            mx = fmaxf(mx, agg_logit(pk));
+        }
+        const float l0 = agg_logit(bgp);
+        mx = fmaxf(mx, l0);
+        float den = expf(l0 - mx);
+        for (int k = 0; k < K; ++k) den += expf(agg_logit(masks[(size_t)k * P + e]) - mx);
+        prob[e] = expf(l0 - mx) / den;
+        for (int k = 0; k < K; ++k) prob[(size_t)(k + 1) * P + e] = expf(agg_logit(masks[(size_t)k * P + e]) - mx) / den;
+    }
+}
+
+extern "C" int xmem_aggregate_masks(const float* masks, float* prob, int K, int H, int W, void* stream) {
+    if (!masks || !prob || K <= 0 || H <= 0 || W <= 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(aggregate_masks_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, masks, prob, K, H * W);
+    return xmem_check_launch();
+}
+
+// mask given on a frame that was also segmented (inference_core.py:117-127): objects whose label is valid take
+// the given mask, the others keep the prediction, zeroed wherever any given mask is set.
+__global__ void merge_masks_kernel(const float* __restrict__ pred, const float* __restrict__ mask, unsigned long long valid_bits,
+                                   float* __restrict__ out, int K, int P) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += mask[(size_t)k * P + e];
+        const bool region = s > 0.5f;
+        for (int k = 0; k < K; ++k) {
+            const bool valid = (valid_bits >> k) & 1ull;
+            out[(size_t)k * P + e] = valid ? mask[(size_t)k * P + e] : (region ? 0.f : pred[(size_t)k * P + e]);
+        }
+    }
+}
+
+extern "C" int xmem_merge_masks(const float* pred_no_bg, const float* mask, uint64_t valid_bits, float* out, int K, int H, int W, void* stream) {
+    if (!pred_no_bg || !mask || !out || K <= 0 || K > 64 || H <= 0 || W <= 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(merge_masks_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, pred_no_bg, mask,
+                       (unsigned long long)valid_bits, out, K, H * W);
+    return xmem_check_launch();
+}
+
+// F.interpolate(prob.unsqueeze(1), shape, mode='bilinear', align_corners=False) (run_on_video.py:166-168)
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int Hi, int Wi, int Ho, int Wo) {
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    const size_t total = (size_t)C * Ho * Wo;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % Wo); const int y = (int)((e / Wo) % Ho); const int c = (int)(e / ((size_t)Wo * Ho));
+        int y0, y1, x0, x1; float ly, lx;
+        bilinear_src(y, sy, Hi, y0, y1, ly);
+        bilinear_src(x, sx, Wi, x0, x1, lx);
+        const float* p = in + (size_t)c * Hi * Wi;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        out[e] = hy * (hx * p[(size_t)y0 * Wi + x0] + lx * p[(size_t)y0 * Wi + x1]) +
+                 ly * (hx * p[(size_t)y1 * Wi + x0] + lx * p[(size_t)y1 * Wi + x1]);
+    }
+}
+
+extern "C" int xmem_resize_bilinear(const float* in, float* out, int C, int Hi, int Wi, int Ho, int Wo, void* stream) {
+    if (!in || !out || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for((size_t)C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in, out, C, Hi, Wi, Ho, Wo);
+    return xmem_check_launch();
+}
+
+__global__ void argmax_u8_kernel(const float* __restrict__ prob, uint8_t* __restrict__ out, int C, int P) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < P; e += gridDim.x * blockDim.x) {
+        float best = prob[e]; int bi = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = prob[(size_t)c * P + e];
+            if (v > best) { best = v; bi = c; }     // first maximal index, as torch.argmax
+        }
+        out[e] = (uint8_t)bi;
+    }
+}
+
+extern "C" int xmem_argmax_u8(const float* prob, uint8_t* out, int C, int H, int W, void* stream) {
+    if (!prob || !out || C <= 0 || C > 255 || H <= 0 || W <= 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(argmax_u8_kernel, dim3(grid_for((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, prob, out, C, H * W);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout transposes through a padded LDS tile (32 pixels x 32 channels)
+// ---------------------------------------------------------------------------------------------
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int ld, float* __restrict__ out, int P, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int pidx = p0 + r, c = c0 + tx;
+        tile[r][tx] = (pidx < P && c < C) ? in[((size_t)b * P + pidx) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, pidx = p0 + tx;
+        if (pidx < P && c < C) out[((size_t)b * C + c) * P + pidx] = tile[tx][r];
+    }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int ld, int P, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, pidx = p0 + tx;
+        tile[r][tx] = (pidx < P && c < C) ? in[((size_t)b * C + c) * P + pidx] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int pidx = p0 + r, c = c0 + tx;
+        if (pidx < P && c < C) out[((size_t)b * P + pidx) * ld + c] = tile[tx][r];
+    }
+}
+
+extern "C" int xmem_nhwc_to_nchw(const float* in, int ld, float* out, int B, int P, int C, void* stream) {
+    if (!in || !out || B <= 0 || P <= 0 || C <= 0 || ld < C) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(P, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, ld, out, P, C);
+    return xmem_check_launch();
+}
+
+extern "C" int xmem_nchw_to_nhwc(const float* in, float* out, int ld, int B, int P, int C, void* stream) {
+    if (!in || !out || B <= 0 || P <= 0 || C <= 0 || ld < C) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(P, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, ld, P, C);
+    return xmem_check_launch();
+}

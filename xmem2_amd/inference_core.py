@@ -1,0 +1,173 @@
+"""Per-frame state machine: the reference's ``InferenceCore`` surface (inference/inference_core.py:11-185)
+driving the HIP kernels.  ``step()``, ``put_to_permanent_memory()``, ``clear_memory()``, ``update_config()``,
+``set_all_labels()``, ``encode_frame_key()``, ``remove_from_permanent_memory()`` and
+``permanent_memory_frames`` keep the reference's signatures and semantics; tensors enter and leave in the
+reference's conventions (image ``3 x H x W`` float32 normalised, mask ``K x H x W``, prob ``(K+1) x H x W``).
+"""
+import torch
+
+from . import ops
+from .memory_manager import MemoryManager
+from .tensor_util import pad_amounts
+
+
+class InferenceCore:
+    def __init__(self, network, config):
+        self.config = config
+        self.network = network
+        self._read_config(config)
+        self.clear_memory()
+        self.all_labels = None
+        # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
+        if getattr(network, 'device', None) is not None and network.device.type == 'cuda':
+            with torch.cuda.device(network.device):
+                self.network.encode_key_nhwc(torch.zeros((1, 64, 64, 4), device=network.device))
+
+    def _read_config(self, config):
+        self.mem_every = config['mem_every']
+        self.deep_update_every = config['deep_update_every']
+        self.enable_long_term = config['enable_long_term']
+        self.deep_update_sync = (self.deep_update_every < 0)   # < 0: deep update synchronised with memory frames
+
+    def clear_memory(self, keep_permanent=False):
+        """inference_core.py:28-38."""
+        self.curr_ti = -1
+        self.last_mem_ti = 0
+        if not self.deep_update_sync:
+            self.last_deep_update_ti = -self.deep_update_every
+        self.memory = self.memory.copy_perm_mem_only() if keep_permanent else MemoryManager(config=self.config)
+
+    def update_config(self, config):
+        """inference_core.py:40-47."""
+        self._read_config(config)
+        self.memory.update_config(config)
+
+    def set_all_labels(self, all_labels):
+        self.all_labels = all_labels
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def _pack(self, image):
+        if image.dim() != 3 or image.shape[0] != 3:
+            raise NotImplementedError('image must be 3 x H x W')
+        H, W = image.shape[-2:]
+        lw, uw, lh, uh = pad_amounts(H, W, 16)
+        self.pad = (lw, uw, lh, uh)
+        if image.dtype != torch.float32:
+            image = image.float()
+        return ops.pack_image(image, H + lh + uh, W + lw + uw, lh, lw), (H, W), (H + lh + uh, W + lw + uw)
+
+    def _pad_mask(self, mask, hw, hw_p):
+        mask = mask.to(dtype=torch.float32)
+        if hw == hw_p:
+            return mask.contiguous()
+        out = torch.zeros((mask.shape[0],) + tuple(hw_p), dtype=torch.float32, device=mask.device)
+        lw, uw, lh, uh = self.pad
+        out[:, lh:lh + hw[0], lw:lw + hw[1]].copy_(mask)
+        return out
+
+    def _key_views(self, key, shrinkage, selection, h, w):
+        ck = key.shape[1]
+        k = key.view(1, h, w, ck).permute(0, 3, 1, 2)
+        s = shrinkage.view(1, 1, h, w) if shrinkage is not None else None
+        e = selection.view(1, h, w, ck).permute(0, 3, 1, 2) if selection is not None else None
+        return k, s, e
+
+    def encode_frame_key(self, image):
+        """inference_core.py:53-61."""
+        image4, _, _ = self._pack(image)
+        key, shr, sel, f16, _, _ = self.network.encode_key_nhwc(image4, need_sk=True, need_ek=True)
+        return self._key_views(key, shr, sel, f16.shape[1], f16.shape[2])
+
+    # ---- the per-frame step ----------------------------------------------------------------------
+    def step(self, image, mask=None, valid_labels=None, end=False, manually_curated_masks=False,
+             disable_memory_updates=False, do_not_add_mask_to_memory=False, return_key_and_stuff=False):
+        """inference_core.py:62-152.  image: 3*H*W, mask: num_objects*H*W or None -> prob (K+1)*H*W."""
+        self.curr_ti += 1
+        image4, hw, hw_p = self._pack(image)
+        if manually_curated_masks:
+            is_mem_frame = (mask is not None) and (not end)
+        else:
+            is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)
+        is_ignore = do_not_add_mask_to_memory
+        need_segment = (valid_labels is None) or (len(self.all_labels) != len(valid_labels))
+        is_deep_update = ((self.deep_update_sync and is_mem_frame) or
+                          (not self.deep_update_sync and self.curr_ti - self.last_deep_update_ti >= self.deep_update_every)
+                          ) and (not end)
+        is_normal_update = (not self.deep_update_sync or not is_deep_update) and (not end)
+
+        net, mem = self.network, self.memory
+        key, shrinkage, selection, f16, f8, f4 = net.encode_key_nhwc(
+            image4, need_sk=True, need_ek=(self.enable_long_term or need_segment))
+        h, w = f16.shape[1], f16.shape[2]
+
+        if disable_memory_updates:
+            is_normal_update = is_deep_update = is_mem_frame = False
+            self.curr_ti -= 1
+
+        prob = prob_padded = None
+        if need_segment:
+            hidden = mem.get_hidden()
+            K = hidden.shape[0]
+            cat16 = net.new_decoder_input(K, h, w, f16.device)
+            ld = cat16.shape[3]
+            mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024,
+                                  disable_usage_updates=disable_memory_updates)
+            new_hidden, prob, prob_padded = net.segment_nhwc(f16, f8, f4, cat16, hidden, hw, (self.pad[2], self.pad[0]),
+                                                             h_out=is_normal_update)
+            if is_normal_update:
+                mem.set_hidden(new_hidden)
+
+        if mask is not None:
+            mask_p = self._pad_mask(mask, hw, hw_p)
+            if prob_padded is not None:
+                bits = (1 << mask_p.shape[0]) - 1
+                if valid_labels is not None:
+                    bits = 0
+                    for i in range(mask_p.shape[0]):
+                        if (i + 1) in valid_labels:
+                            bits |= (1 << i)
+                mask_p = ops.merge_masks(prob_padded[1:], mask_p, bits)
+            prob_padded = ops.aggregate_masks(mask_p)
+            lw, _, lh, _ = self.pad
+            prob = prob_padded[:, lh:lh + hw[0], lw:lw + hw[1]]
+            if not disable_memory_updates:
+                mem.create_hidden_state(len(self.all_labels), hw_shape=(h, w), device=f16.device)
+
+        if is_mem_frame:
+            value, hidden = net.encode_value_nhwc(image4, f16, mem.get_hidden(), prob_padded[1:],
+                                                  is_deep_update=is_deep_update)
+            mem.add_memory(key, shrinkage, value.view(value.shape[0], h * w, value.shape[3]), self.all_labels,
+                           selection=selection if self.enable_long_term else None, ignore=is_ignore, hw_shape=(h, w))
+            self.last_mem_ti = self.curr_ti
+            if is_deep_update:
+                mem.set_hidden(hidden)
+                self.last_deep_update_ti = self.curr_ti
+
+        if return_key_and_stuff:
+            return (prob,) + self._key_views(key, shrinkage, selection, h, w)
+        return prob
+
+    def put_to_permanent_memory(self, image, mask, ti=None):
+        """inference_core.py:154-179."""
+        image4, hw, hw_p = self._pack(image)
+        net, mem = self.network, self.memory
+        key, shrinkage, selection, f16, _, _ = net.encode_key_nhwc(image4, need_sk=True, need_ek=True)
+        h, w = f16.shape[1], f16.shape[2]
+        prob_padded = ops.aggregate_masks(self._pad_mask(mask, hw, hw_p))
+        mem.create_hidden_state(len(self.all_labels), hw_shape=(h, w), device=f16.device)
+        value, _ = net.encode_value_nhwc(image4, f16, mem.get_hidden(), prob_padded[1:], is_deep_update=False)
+        value = value.view(value.shape[0], h * w, value.shape[3])
+        is_update = mem.frame_already_saved(ti)
+        sel = selection if self.enable_long_term else None
+        if is_update:
+            mem.update_permanent_memory(ti, key, shrinkage, value, selection=sel)
+        else:
+            mem.add_memory(key, shrinkage, value, self.all_labels, selection=sel, permanent=True, ti=ti, hw_shape=(h, w))
+        return is_update
+
+    def remove_from_permanent_memory(self, frame_idx):
+        self.memory.remove_from_permanent_memory(frame_idx)
+
+    @property
+    def permanent_memory_frames(self):
+        return list(self.memory.frame_id_to_permanent_mem_idx.keys())

@@ -1,0 +1,377 @@
+"""XMem network on MI355X: the reference's ``XMem`` surface (model/network.py:17-198) over HIP kernels.
+
+``XMem(config, model_path, map_location, ...)`` keeps the constructor, ``encode_key`` / ``encode_value`` /
+``segment`` / ``load_weights`` and the 412-name state_dict of the reference, so an upstream ``XMem.pth``
+loads unchanged.  Internally nothing is an nn.Module: at load time every convolution is re-laid-out to
+``[Cout][KH][KW][Cin]`` with its eval-mode BatchNorm folded to a per-channel (scale, shift) epilogue
+(ATen's own alpha/beta form), and every activation lives in NHWC so that the implicit-GEMM kernel
+(csrc/conv_mfma.hip) reads K-contiguous operands.
+
+Public methods take / return NCHW-shaped tensors like the reference (zero-copy permuted views of the
+NHWC buffers); the ``*_nhwc`` methods are the hot path used by ``InferenceCore``.
+"""
+import warnings
+
+import torch
+
+from . import ops
+from .arch import BN_EPS, infer_dims, state_dict_spec
+from .ops import ConvWeights
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class XMem:
+    def __init__(self, config, model_path=None, map_location=None, pretrained_key_encoder=True, pretrained_value_encoder=True):
+        """Same signature as model/network.py:18.  `pretrained_*` are accepted for compatibility; torchvision
+        ImageNet weights cannot be fetched offline, so a checkpoint (or load_weights) is the only weight source."""
+        self.single_object = config.get('single_object', False)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+        self._sd = None
+        self._w = {}
+        self._cbam = {}
+        weights = self.init_hyperparameters(config, model_path, map_location)
+        if weights is not None:
+            self.load_weights(weights, init_as_zero_if_needed=True)
+
+    # ---- reference surface --------------------------------------------------------------------
+    def init_hyperparameters(self, config, model_path=None, map_location=None):
+        """model/network.py:134-182: C_k/C_v/C_h from the checkpoint if given, else config/defaults; writes them back."""
+        if model_path is not None:
+            weights = torch.load(model_path, map_location=map_location or 'cpu')
+            self.key_dim, self.value_dim, self.hidden_dim = infer_dims(weights)
+            self.disable_hidden = self.hidden_dim == 0
+        else:
+            weights = None
+            self.key_dim = config.get('key_dim', 64)
+            self.value_dim = config.get('value_dim', 512)
+            self.hidden_dim = config.get('hidden_dim', 64)
+            self.disable_hidden = self.hidden_dim <= 0
+        config['key_dim'], config['value_dim'], config['hidden_dim'] = self.key_dim, self.value_dim, self.hidden_dim
+        return weights
+
+    def load_weights(self, src_dict, init_as_zero_if_needed=False):
+        """model/network.py:184-198: pads a single-object 4-channel value stem to the 5-channel multi-object one."""
+        src_dict = dict(src_dict)
+        k = 'value_encoder.conv1.weight'
+        if k in src_dict and src_dict[k].shape[1] == 4 and not self.single_object:
+            pads = torch.zeros((64, 1, 7, 7), device=src_dict[k].device)
+            if not init_as_zero_if_needed:
+                torch.nn.init.orthogonal_(pads)
+            src_dict[k] = torch.cat([src_dict[k], pads], 1)
+        self.load_state_dict(src_dict)
+
+    def load_state_dict(self, sd, strict=True):
+        spec = state_dict_spec(self.key_dim, self.value_dim, self.hidden_dim, self.single_object)
+        if strict:
+            missing = [k for k in spec if k not in sd and not k.endswith('num_batches_tracked')]
+            unexpected = [k for k in sd if k not in spec]
+            if missing or unexpected:
+                raise RuntimeError(f'Error(s) in loading state_dict for XMem: missing {missing[:5]}..., unexpected {unexpected[:5]}...')
+            for k, shape in spec.items():
+                if k in sd and tuple(sd[k].shape) != tuple(shape):
+                    raise RuntimeError(f'size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(shape)}')
+        self._sd = {k: v.detach().to('cpu') for k, v in sd.items()}
+        if self.device.type == 'cuda':
+            self._upload()
+
+    def state_dict(self):
+        return dict(self._sd) if self._sd is not None else {}
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = device
+        if device.type == 'cuda' and self._sd is not None:
+            self._upload()
+        return self
+
+    def cuda(self, index=None):
+        return self.to(torch.device('cuda', index if index is not None else torch.cuda.current_device()))
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError('xmem2_amd.XMem is inference-only (training is out of scope, SURVEY.md section 2 #19)')
+        return self
+
+    # ---- weight preparation ---------------------------------------------------------------------
+    def _conv_w(self, name, bn=None, stride=1, pad=0):
+        sd = self._sd
+        w = sd[name + '.weight'].float()
+        cout, cin = w.shape[0], w.shape[1]
+        wk = w.permute(0, 2, 3, 1)
+        if cin % 4:
+            wk = torch.nn.functional.pad(wk, (0, _pad4(cin) - cin))
+        if bn is not None:
+            invstd = 1.0 / torch.sqrt(sd[bn + '.running_var'].float() + BN_EPS)
+            scale = invstd * sd[bn + '.weight'].float()
+            shift = sd[bn + '.bias'].float() - sd[bn + '.running_mean'].float() * scale
+        else:
+            scale = torch.ones(cout)
+            shift = sd[name + '.bias'].float() if (name + '.bias') in sd else torch.zeros(cout)
+        dev = self.device
+        return ConvWeights(wk.contiguous().to(dev), scale.contiguous().to(dev), shift.contiguous().to(dev), stride, pad)
+
+    def _upload(self):
+        sd, W = self._sd, {}
+        W['key_encoder.conv1'] = self._conv_w('key_encoder.conv1', 'key_encoder.bn1', 2, 3)
+
+        def bottleneck_stage(prefix, blocks, stride):
+            for b in range(blocks):
+                p, s = f'{prefix}.{b}', (stride if b == 0 else 1)
+                W[p + '.conv1'] = self._conv_w(p + '.conv1', p + '.bn1', 1, 0)
+                W[p + '.conv2'] = self._conv_w(p + '.conv2', p + '.bn2', s, 1)
+                W[p + '.conv3'] = self._conv_w(p + '.conv3', p + '.bn3', 1, 0)
+                if (p + '.downsample.0.weight') in sd:
+                    W[p + '.downsample'] = self._conv_w(p + '.downsample.0', p + '.downsample.1', s, 0)
+
+        def basic_stage(prefix, blocks, stride):
+            for b in range(blocks):
+                p, s = f'{prefix}.{b}', (stride if b == 0 else 1)
+                W[p + '.conv1'] = self._conv_w(p + '.conv1', p + '.bn1', s, 1)
+                W[p + '.conv2'] = self._conv_w(p + '.conv2', p + '.bn2', 1, 1)
+                if (p + '.downsample.0.weight') in sd:
+                    W[p + '.downsample'] = self._conv_w(p + '.downsample.0', p + '.downsample.1', s, 0)
+
+        bottleneck_stage('key_encoder.res2', 3, 1)
+        bottleneck_stage('key_encoder.layer2', 4, 2)
+        bottleneck_stage('key_encoder.layer3', 6, 2)
+        W['value_encoder.conv1'] = self._conv_w('value_encoder.conv1', 'value_encoder.bn1', 2, 3)
+        if W['value_encoder.conv1'].cin != 8:       # 5 (or 4) input channels live in an 8-channel packed tensor
+            cw = W['value_encoder.conv1']
+            wk = torch.nn.functional.pad(cw.w, (0, 8 - cw.cin))
+            W['value_encoder.conv1'] = ConvWeights(wk.contiguous(), cw.scale, cw.shift, 2, 3)
+        basic_stage('value_encoder.layer1', 2, 1)
+        basic_stage('value_encoder.layer2', 2, 2)
+        basic_stage('value_encoder.layer3', 2, 2)
+
+        def group_res(p):
+            if (p + '.downsample.weight') in sd:
+                W[p + '.downsample'] = self._conv_w(p + '.downsample', None, 1, 1)
+            W[p + '.conv1'] = self._conv_w(p + '.conv1', None, 1, 1)
+            W[p + '.conv2'] = self._conv_w(p + '.conv2', None, 1, 1)
+
+        def fusion(p):
+            group_res(p + '.block1')
+            group_res(p + '.block2')
+            a = p + '.attention'
+            dev = self.device
+            self._cbam[a] = dict(
+                w1=sd[a + '.ChannelGate.mlp.1.weight'].float().contiguous().to(dev),
+                b1=sd[a + '.ChannelGate.mlp.1.bias'].float().contiguous().to(dev),
+                w2=sd[a + '.ChannelGate.mlp.3.weight'].float().contiguous().to(dev),
+                b2=sd[a + '.ChannelGate.mlp.3.bias'].float().contiguous().to(dev),
+                sw=sd[a + '.SpatialGate.spatial.conv.weight'].float().reshape(2, 7, 7).contiguous().to(dev),
+                sb=sd[a + '.SpatialGate.spatial.conv.bias'].float().contiguous().to(dev))
+
+        fusion('value_encoder.fuser')
+        fusion('decoder.fuser')
+        if self.hidden_dim > 0:
+            W['value_encoder.hidden_reinforce.transform'] = self._conv_w('value_encoder.hidden_reinforce.transform', None, 1, 1)
+            W['decoder.hidden_update.g16_conv'] = self._conv_w('decoder.hidden_update.g16_conv', None, 1, 0)
+            W['decoder.hidden_update.g8_conv'] = self._conv_w('decoder.hidden_update.g8_conv', None, 1, 0)
+            W['decoder.hidden_update.g4_conv'] = self._conv_w('decoder.hidden_update.g4_conv', None, 1, 0)
+            W['decoder.hidden_update.transform'] = self._conv_w('decoder.hidden_update.transform', None, 1, 1)
+        W['decoder.up_16_8.skip_conv'] = self._conv_w('decoder.up_16_8.skip_conv', None, 1, 1)
+        group_res('decoder.up_16_8.out_conv')
+        W['decoder.up_8_4.skip_conv'] = self._conv_w('decoder.up_8_4.skip_conv', None, 1, 1)
+        group_res('decoder.up_8_4.out_conv')
+        W['decoder.pred'] = self._conv_w('decoder.pred', None, 1, 1)
+        # KeyProjection: key | shrinkage | selection share one implicit GEMM (Cout = 2*C_k + 1)
+        parts = [self._conv_w('key_proj.' + n, None, 1, 1) for n in ('key_proj', 'd_proj', 'e_proj')]
+        W['key_proj'] = ConvWeights(torch.cat([p.w for p in parts], 0).contiguous(),
+                                    torch.cat([p.scale for p in parts], 0).contiguous(),
+                                    torch.cat([p.shift for p in parts], 0).contiguous(), 1, 1)
+        self._w = W
+
+    def _need_weights(self):
+        if not self._w:
+            if self._sd is None:
+                warnings.warn('XMem: no checkpoint loaded - using the deterministic synthetic weights (xmem2_amd.synth)')
+                from .synth import synthetic_state_dict
+                self._sd = synthetic_state_dict(0, self.key_dim, self.value_dim, self.hidden_dim)
+            if self.device.type != 'cuda':
+                raise RuntimeError('xmem2_amd.XMem runs on an MI355X (HIP) device only; call .to("cuda") - there is no CPU path')
+            self._upload()
+
+    # ---- building blocks (NHWC) -----------------------------------------------------------------
+    def _bottleneck(self, x, p):
+        W = self._w
+        o = ops.conv2d(x, W[p + '.conv1'], relu_out=True)
+        o = ops.conv2d(o, W[p + '.conv2'], relu_out=True)
+        res = ops.conv2d(x, W[p + '.downsample']) if (p + '.downsample') in W else x
+        return ops.conv2d(o, W[p + '.conv3'], res=res, relu_out=True)
+
+    def _basic(self, x, p):
+        W = self._w
+        o = ops.conv2d(x, W[p + '.conv1'], relu_out=True)
+        res = ops.conv2d(x, W[p + '.downsample']) if (p + '.downsample') in W else x
+        return ops.conv2d(o, W[p + '.conv2'], res=res, relu_out=True)
+
+    def _stage(self, x, prefix, blocks, fn):
+        for b in range(blocks):
+            x = fn(x, f'{prefix}.{b}')
+        return x
+
+    def _group_res(self, g, p, out=None, out_ld=None):
+        """GroupResBlock, model/group_modules.py:44-52: conv2(relu(conv1(relu(g)))) + (downsample(g) | g)."""
+        W = self._w
+        o = ops.conv2d(g, W[p + '.conv1'], relu_in=True, relu_out=True)
+        res = ops.conv2d(g, W[p + '.downsample']) if (p + '.downsample') in W else g
+        return ops.conv2d(o, W[p + '.conv2'], res=res, out=out, out_ld=out_ld)
+
+    def _fusion(self, cat, p):
+        """FeatureFusionBlock, model/modules.py:31-41, on the already concatenated [x | g] tensor."""
+        g = self._group_res(cat, p + '.block1')
+        g = ops.cbam_residual(g, self._cbam[p + '.attention'])
+        return self._group_res(g, p + '.block2')
+
+    # ---- hot path (NHWC) ------------------------------------------------------------------------
+    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True):
+        """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC)."""
+        self._need_weights()
+        W = self._w
+        x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
+        x = ops.maxpool3x3s2(x)
+        f4 = self._stage(x, 'key_encoder.res2', 3, self._bottleneck)
+        f8 = self._stage(f4, 'key_encoder.layer2', 4, self._bottleneck)
+        f16 = self._stage(f8, 'key_encoder.layer3', 6, self._bottleneck)
+        B, h, w, _ = f16.shape
+        ld = _pad4(2 * self.key_dim + 1)
+        proj = torch.empty((B, h, w, ld), dtype=torch.float32, device=f16.device)
+        ops.conv2d(f16, W['key_proj'], out=proj, out_ld=ld)
+        key, shr, sel = ops.key_post(proj, self.key_dim, need_sk, need_ek)
+        return key, shr, sel, f16, f8, f4
+
+    def encode_value_nhwc(self, image4, f16, hidden, masks, is_deep_update=True):
+        """image4 [1,Hp,Wp,4], f16 [1,h,w,1024], hidden [K,h,w,Ch], masks [K,Hp,Wp] -> value [K,h,w,Cv], hidden."""
+        self._need_weights()
+        W = self._w
+        x = ops.pack_value_input(image4, masks)
+        g = ops.conv2d(x, W['value_encoder.conv1'], relu_out=True)     # relu and max-pool commute (modules.py:137-138)
+        g = ops.maxpool3x3s2(g)
+        g = self._stage(g, 'value_encoder.layer1', 2, self._basic)
+        g = self._stage(g, 'value_encoder.layer2', 2, self._basic)
+        g = self._stage(g, 'value_encoder.layer3', 2, self._basic)
+        K, h, w, cg = g.shape
+        cat = torch.empty((K, h, w, f16.shape[3] + cg), dtype=torch.float32, device=g.device)
+        ops.copy_channels(f16, cat, 0)
+        ops.copy_channels(g, cat, f16.shape[3])
+        value = self._fusion(cat, 'value_encoder.fuser')
+        if is_deep_update and self.hidden_dim > 0:
+            cat2 = torch.empty((K, h, w, self.value_dim + self.hidden_dim), dtype=torch.float32, device=g.device)
+            ops.copy_channels(value, cat2, 0)
+            ops.copy_channels(hidden, cat2, self.value_dim)
+            values = ops.conv2d(cat2, W['value_encoder.hidden_reinforce.transform'])
+            hidden = ops.gru_gate(values, hidden)
+        return value, hidden
+
+    def new_decoder_input(self, K, h, w, device):
+        """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place."""
+        return torch.empty((K, h, w, 1024 + self.value_dim + self.hidden_dim), dtype=torch.float32, device=device)
+
+    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True):
+        """Decoder + soft aggregation.  cat16 holds the memory readout at channels [1024,1024+Cv).
+        Returns new_hidden|None, prob [K+1,H,W] (unpadded), prob_padded [K+1,Hp,Wp]."""
+        self._need_weights()
+        W = self._w
+        K, h, w, _ = cat16.shape
+        hd = self.hidden_dim
+        ops.copy_channels(f16, cat16, 0)
+        if hd > 0:
+            ops.copy_channels(hidden, cat16, 1024 + self.value_dim)
+        g16 = self._fusion(cat16, 'decoder.fuser')
+        skip8 = ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
+        g8 = self._group_res(ops.upsample2x_add(g16, skip8), 'decoder.up_16_8.out_conv')
+        skip4 = ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
+        g4 = self._group_res(ops.upsample2x_add(g8, skip4), 'decoder.up_8_4.out_conv')
+        logits = ops.conv2d(g4, W['decoder.pred'], relu_in=True)          # [K,4h,4w,1]
+        new_hidden = None
+        if h_out and hd > 0:
+            c4 = g4.shape[3]
+            g4d = torch.zeros((K, h, w, _pad4(c4 + 1)), dtype=torch.float32, device=g4.device)
+            ops.area_downsample(g4, 4, out=g4d, out_ld=g4d.shape[3])
+            ops.area_downsample(logits, 4, out=g4d, out_ld=g4d.shape[3], out_off=c4)
+            g8d = ops.area_downsample(g8, 2)
+            t = ops.conv2d(g16, W['decoder.hidden_update.g16_conv'])
+            t = ops.conv2d(g8d, W['decoder.hidden_update.g8_conv'], res=t)
+            cat = torch.empty((K, h, w, t.shape[3] + hd), dtype=torch.float32, device=g4.device)
+            ops.conv2d(g4d, W['decoder.hidden_update.g4_conv'], res=t, out=cat, out_ld=cat.shape[3])
+            ops.copy_channels(hidden, cat, t.shape[3])
+            values = ops.conv2d(cat, W['decoder.hidden_update.transform'])
+            new_hidden = ops.gru_gate(values, hidden)
+        H, Wd = out_hw
+        prob, prob_padded = ops.logits_to_prob(logits.view(K, 4 * h, 4 * w), H, Wd, pad_tl[0], pad_tl[1])
+        return new_hidden, prob, prob_padded
+
+    # ---- reference-shaped wrappers (NCHW in / out) ----------------------------------------------
+    @staticmethod
+    def _as_nhwc(t):
+        p = t.permute(0, 2, 3, 1)
+        return p if p.is_contiguous() else ops.nchw_to_nhwc(t)
+
+    def encode_key(self, frame, need_sk=True, need_ek=True):
+        """model/network.py:40-70 for 4-D input [B,3,H,W] (H, W multiples of 16)."""
+        if frame.dim() != 4:
+            raise NotImplementedError
+        B, _, H, Wd = frame.shape
+        image4 = torch.cat([ops.pack_image(frame[b], H, Wd, 0, 0) for b in range(B)], 0) if B > 1 \
+            else ops.pack_image(frame[0], H, Wd, 0, 0)
+        key, shr, sel, f16, f8, f4 = self.encode_key_nhwc(image4, need_sk, need_ek)
+        h, w = f16.shape[1], f16.shape[2]
+        nchw = lambda t: t.permute(0, 3, 1, 2)
+        key = nchw(key.view(B, h, w, self.key_dim))
+        shr = shr.view(B, 1, h, w) if shr is not None else None
+        sel = nchw(sel.view(B, h, w, self.key_dim)) if sel is not None else None
+        self._last_image4 = (frame.data_ptr(), image4)
+        return key, shr, sel, nchw(f16), nchw(f8), nchw(f4)
+
+    def encode_value(self, frame, image_feat_f16, h16, masks, is_deep_update=True):
+        """model/network.py:72-85: frame [1,3,H,W], f16 [1,1024,h,w], h16 [1,K,Ch,h,w], masks [1,K,H,W]."""
+        cached = getattr(self, '_last_image4', None)
+        if cached is not None and cached[0] == frame.data_ptr():
+            image4 = cached[1]
+        else:
+            image4 = ops.pack_image(frame[0], frame.shape[2], frame.shape[3], 0, 0)
+        f16 = self._as_nhwc(image_feat_f16)
+        hidden = self._as_nhwc(h16[0]) if h16 is not None else None
+        m = masks[0] if masks[0].is_contiguous() else masks[0].contiguous()
+        value, hidden = self.encode_value_nhwc(image4, f16, hidden, m, is_deep_update)
+        value = value.permute(0, 3, 1, 2).unsqueeze(0)
+        hidden = hidden.permute(0, 3, 1, 2).unsqueeze(0) if hidden is not None else None
+        return value, hidden
+
+    def segment(self, multi_scale_features, memory_readout, hidden_state, selector=None, h_out=True, strip_bg=True):
+        """model/network.py:107-120.  Returns (hidden, None, prob): the aggregated logits are a training-only
+        output of the reference and are not produced here."""
+        if selector is not None:
+            raise NotImplementedError('selector is a training-time argument (model/trainer.py) - out of scope')
+        f16, f8, f4 = [self._as_nhwc(t) for t in multi_scale_features]
+        ro = self._as_nhwc(memory_readout[0])                      # [K,h,w,Cv]
+        K, h, w, _ = ro.shape
+        hidden = self._as_nhwc(hidden_state[0]) if hidden_state is not None else None
+        cat16 = self.new_decoder_input(K, h, w, ro.device)
+        ops.copy_channels(ro, cat16, 1024)
+        new_hidden, _, prob = self.segment_nhwc(f16, f8, f4, cat16, hidden, (16 * h, 16 * w), (0, 0), h_out)
+        prob = prob.unsqueeze(0)
+        if strip_bg:
+            prob = prob[:, 1:]
+        new_hidden = new_hidden.permute(0, 3, 1, 2).unsqueeze(0) if new_hidden is not None else None
+        return new_hidden, None, prob
+
+    def forward(self, mode, *args, **kwargs):
+        if mode == 'encode_key':
+            return self.encode_key(*args, **kwargs)
+        if mode == 'encode_value':
+            return self.encode_value(*args, **kwargs)
+        if mode == 'segment':
+            return self.segment(*args, **kwargs)
+        raise NotImplementedError(mode)
+
+    __call__ = forward

@@ -1,0 +1,319 @@
+"""Tensor-level wrappers over the C-ABI kernels.
+
+Everything here takes / returns torch CUDA tensors in the kernels' native layouts (NHWC activations
+``[B,H,W,C]``, row-major memory rows ``[N,C]``) and launches on torch's current HIP stream.
+torch is plumbing only: allocation, streams.  No torch compute op is used on the product path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_ptr
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so reuse is safe."""
+    key = (str(device), tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _req(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: expected a CUDA (HIP) tensor - xmem2_amd has no CPU path')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'{name}: expected float32')
+    return t
+
+
+class ConvWeights:
+    """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
+    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad')
+
+    def __init__(self, w, scale, shift, stride, pad):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.cout, self.kh, self.kw, self.cin = w.shape
+        self.stride, self.pad = stride, pad
+
+
+def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None):
+    """x [B,H,W,C] NHWC (or any buffer whose pixel stride is `in_ld`) -> out [B,Ho,Wo,Cout]."""
+    lib = load()
+    _req(x, 'conv2d input')
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    ldin = in_ld if in_ld is not None else x.shape[3]
+    cin = cin if cin is not None else cw.cin
+    if cin != cw.cin:
+        raise RuntimeError(f'conv2d: weight expects Cin={cw.cin}, got {cin}')
+    Ho = (H + 2 * cw.pad - cw.kh) // cw.stride + 1
+    Wo = (W + 2 * cw.pad - cw.kw) // cw.stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float32, device=x.device)
+        out_ld = cw.cout
+    elif out_ld is None:
+        out_ld = out.shape[-1]
+    d = ConvDesc()
+    d.inp = x.data_ptr(); d.B, d.H, d.W, d.Cin, d.ldin = B, H, W, cin, ldin
+    d.w = cw.w.data_ptr(); d.Cout, d.KH, d.KW, d.stride, d.pad = cw.cout, cw.kh, cw.kw, cw.stride, cw.pad
+    d.scale = cw.scale.data_ptr(); d.shift = cw.shift.data_ptr()
+    d.res = res.data_ptr() if res is not None else None
+    d.ldres = res.shape[-1] if res is not None else 0
+    d.out = out.data_ptr(); d.ldout = out_ld
+    d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
+    ws = workspace(need, x.device, 'conv') if need else None
+    check(lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()))
+    return out
+
+
+def maxpool3x3s2(x):
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
+    check(load().xmem_maxpool3x3s2(ptr(x), ptr(out), B, H, W, Cc, stream_ptr()))
+    return out
+
+
+def upsample2x_add(g, skip):
+    B, h, w, Cc = g.shape
+    out = torch.empty((B, 2 * h, 2 * w, Cc), dtype=torch.float32, device=g.device)
+    check(load().xmem_upsample2x_add(ptr(g), ptr(skip), ptr(out), B, h, w, Cc, stream_ptr()))
+    return out
+
+
+def area_downsample(x, r, out=None, out_ld=None, out_off=0, c=None, in_ld=None):
+    B, H, W = x.shape[:3]
+    c = c if c is not None else x.shape[3]
+    in_ld = in_ld if in_ld is not None else x.shape[3]
+    if out is None:
+        out = torch.empty((B, H // r, W // r, c), dtype=torch.float32, device=x.device)
+        out_ld = c
+    check(load().xmem_area_downsample(ptr(x), in_ld, C.c_void_p(out.data_ptr() + 4 * out_off), out_ld, B, H, W, c, r, stream_ptr()))
+    return out
+
+
+def copy_channels(src, dst, dst_off, c=None, src_off=0):
+    """dst[b, p, dst_off:dst_off+c] = src[b % srcB, p, src_off:src_off+c]; src/dst are [B,H,W,C] buffers."""
+    B = dst.shape[0]
+    P = dst.shape[1] * dst.shape[2]
+    c = c if c is not None else src.shape[3]
+    check(load().xmem_copy_channels(C.c_void_p(src.data_ptr() + 4 * src_off), src.shape[3], src.shape[0],
+                                    C.c_void_p(dst.data_ptr() + 4 * dst_off), dst.shape[3], B, P, c, stream_ptr()))
+    return dst
+
+
+def cbam_residual(g, p):
+    """out = g + CBAM(g); p = dict(w1,b1,w2,b2,sw,sb) device tensors."""
+    lib = load()
+    B, H, W, Cc = g.shape
+    out = torch.empty_like(g)
+    need = lib.xmem_cbam_workspace_bytes(B, H * W, Cc)
+    ws = workspace(need, g.device, 'cbam')
+    check(lib.xmem_cbam_residual(ptr(g), ptr(out), B, H, W, Cc, ptr(p['w1']), ptr(p['b1']), ptr(p['w2']), ptr(p['b2']),
+                                 ptr(p['sw']), ptr(p['sb']), ptr(ws), need, stream_ptr()))
+    return out
+
+
+def gru_gate(values, h):
+    B, H, W, Ch = h.shape
+    out = torch.empty_like(h)
+    check(load().xmem_gru_gate(ptr(values), ptr(h), ptr(out), B, H * W, Ch, stream_ptr()))
+    return out
+
+
+def pack_image(img, Hp, Wp, lh, lw):
+    """img [3,H,W] -> [1,Hp,Wp,4] zero padded NHWC."""
+    _req(img, 'image')
+    if not img.is_contiguous():
+        img = img.contiguous()
+    out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img.device)
+    check(load().xmem_pack_image(ptr(img), ptr(out), img.shape[1], img.shape[2], Hp, Wp, lh, lw, stream_ptr()))
+    return out
+
+
+def pack_value_input(image4, masks):
+    """image4 [1,Hp,Wp,4], masks [K,Hp,Wp] -> [K,Hp,Wp,8]."""
+    K, Hp, Wp = masks.shape
+    out = torch.empty((K, Hp, Wp, 8), dtype=torch.float32, device=masks.device)
+    check(load().xmem_pack_value_input(ptr(image4), ptr(masks), ptr(out), K, Hp, Wp, stream_ptr()))
+    return out
+
+
+def key_post(proj, ck, need_s=True, need_e=True):
+    """proj [1,h,w,ld] -> key [h*w,ck], shrinkage [h*w] | None, selection [h*w,ck] | None."""
+    P = proj.shape[0] * proj.shape[1] * proj.shape[2]
+    key = torch.empty((P, ck), dtype=torch.float32, device=proj.device)
+    shr = torch.empty((P,), dtype=torch.float32, device=proj.device) if need_s else None
+    sel = torch.empty((P, ck), dtype=torch.float32, device=proj.device) if need_e else None
+    check(load().xmem_key_post(ptr(proj), proj.shape[3], ptr(key), ptr(shr), ptr(sel), P, ck, stream_ptr()))
+    return key, shr, sel
+
+
+def logits_to_prob(logits, H, W, lh, lw, want_padded=True):
+    """logits [K,h4,w4] -> prob [K+1,H,W] (cropped) and [K+1,4h4,4w4] (padded)."""
+    K, h4, w4 = logits.shape
+    prob = torch.empty((K + 1, H, W), dtype=torch.float32, device=logits.device)
+    padded = torch.empty((K + 1, 4 * h4, 4 * w4), dtype=torch.float32, device=logits.device) if want_padded else None
+    check(load().xmem_logits_to_prob(ptr(logits), ptr(prob), ptr(padded), K, h4, w4, H, W, lh, lw, stream_ptr()))
+    return prob, padded
+
+
+def aggregate_masks(masks):
+    K, H, W = masks.shape
+    if not masks.is_contiguous():
+        masks = masks.contiguous()
+    prob = torch.empty((K + 1, H, W), dtype=torch.float32, device=masks.device)
+    check(load().xmem_aggregate_masks(ptr(_req(masks, 'masks')), ptr(prob), K, H, W, stream_ptr()))
+    return prob
+
+
+def merge_masks(pred_no_bg, mask, valid_bits):
+    K, H, W = mask.shape
+    out = torch.empty_like(mask)
+    check(load().xmem_merge_masks(ptr(pred_no_bg), ptr(mask), valid_bits, ptr(out), K, H, W, stream_ptr()))
+    return out
+
+
+def resize_bilinear(prob, shape):
+    Cc, Hi, Wi = prob.shape
+    if not prob.is_contiguous():
+        prob = prob.contiguous()
+    out = torch.empty((Cc, int(shape[0]), int(shape[1])), dtype=torch.float32, device=prob.device)
+    check(load().xmem_resize_bilinear(ptr(prob), ptr(out), Cc, Hi, Wi, int(shape[0]), int(shape[1]), stream_ptr()))
+    return out
+
+
+def argmax_u8(prob):
+    Cc, H, W = prob.shape
+    if not prob.is_contiguous():
+        prob = prob.contiguous()
+    out = torch.empty((H, W), dtype=torch.uint8, device=prob.device)
+    check(load().xmem_argmax_u8(ptr(_req(prob, 'prob')), ptr(out), Cc, H, W, stream_ptr()))
+    return out
+
+
+def nhwc_to_nchw(x, c=None, off=0):
+    """x [B,H,W,ld] (channels off..off+c) -> contiguous [B,c,H,W]."""
+    B, H, W, ld = x.shape
+    c = c if c is not None else ld
+    out = torch.empty((B, c, H, W), dtype=torch.float32, device=x.device)
+    check(load().xmem_nhwc_to_nchw(C.c_void_p(x.data_ptr() + 4 * off), ld, ptr(out), B, H * W, c, stream_ptr()))
+    return out
+
+
+def nchw_to_nhwc(x):
+    B, c, H, W = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out = torch.empty((B, H, W, c), dtype=torch.float32, device=x.device)
+    check(load().xmem_nchw_to_nhwc(ptr(_req(x, 'tensor')), ptr(out), c, B, H * W, c, stream_ptr()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# memory readout
+# ---------------------------------------------------------------------------------------------
+
+def affinity_topk(segments, qk, qe, top_k, want_sim=False):
+    """segments: list of (key [n,Ck], shrinkage [n] | None).  Returns w [HW,k], idx [HW,k] (int32), sim | None."""
+    lib = load()
+    HW, ck = qk.shape
+    segs = [(k, s) for (k, s) in segments if k is not None and k.shape[0] > 0]
+    n_total = sum(k.shape[0] for k, _ in segs)
+    if n_total < top_k:
+        raise RuntimeError(f'selected index k out of range: top_k={top_k} > {n_total} memory elements')
+    arr = (KeySegment * max(len(segs), 1))()
+    for i, (k, s) in enumerate(segs):
+        arr[i].key = k.data_ptr()
+        arr[i].shrinkage = s.data_ptr() if s is not None else None
+        arr[i].n = k.shape[0]
+    w = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device)
+    idx = torch.empty((HW, top_k), dtype=torch.int32, device=qk.device)
+    sim = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device) if want_sim else None
+    need = lib.xmem_affinity_topk_workspace_bytes(n_total, HW, top_k)
+    ws = workspace(need, qk.device, 'affinity')
+    check(lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
+                                 ptr(ws), need, stream_ptr()))
+    return w, idx, sim
+
+
+def usage_update(w, idx, first, count, use_count, life_count):
+    if count <= 0:
+        return
+    HW, k = w.shape
+    fx = workspace(8 * count, w.device, 'usage_fx')
+    check(load().xmem_usage_update(ptr(w), ptr(idx), HW, k, first, count, ptr(use_count), ptr(life_count), ptr(fx), stream_ptr()))
+
+
+def readout_sparse(value_segments, w, idx, cv, out, out_ld, obj_stride, out_off=0):
+    """value_segments[obj][seg] = tensor [n_seg, Cv] (n may be 0).  Writes out[obj][q][out_off:out_off+Cv]."""
+    n_obj = len(value_segments)
+    n_seg = len(value_segments[0])
+    arr = (ValueSegment * (n_obj * n_seg))()
+    for o, segs in enumerate(value_segments):
+        for s, v in enumerate(segs):
+            arr[o * n_seg + s].value = v.data_ptr() if v is not None and v.shape[0] > 0 else None
+            arr[o * n_seg + s].n = v.shape[0] if v is not None else 0
+    HW, k = w.shape
+    check(load().xmem_readout_sparse(arr, n_obj, n_seg, ptr(w), ptr(idx), HW, k, cv,
+                                     C.c_void_p(out.data_ptr() + 4 * out_off), out_ld, obj_stride, stream_ptr()))
+
+
+def similarity_dense(key, shrinkage, qk, qe):
+    """key [n,Ck], qk/qe [P,Ck] -> sim [P,n]."""
+    n, ck = key.shape
+    P = qk.shape[0]
+    out = torch.empty((P, n), dtype=torch.float32, device=key.device)
+    check(load().xmem_similarity_dense(ptr(key), ptr(shrinkage), n, ptr(qk), ptr(qe), P, ck, ptr(out), stream_ptr()))
+    return out
+
+
+def usage_ratio(use, life):
+    out = torch.empty_like(use)
+    check(load().xmem_usage_ratio(ptr(use), ptr(life), ptr(out), use.numel(), stream_ptr()))
+    return out
+
+
+def topk_1d(values, k, largest=True):
+    idx = torch.empty((k,), dtype=torch.int32, device=values.device)
+    val = torch.empty((k,), dtype=torch.float32, device=values.device)
+    check(load().xmem_topk_1d(ptr(values), values.numel(), k, int(largest), ptr(idx), ptr(val), stream_ptr()))
+    return val, idx
+
+
+def gather_rows(src, index):
+    """src [n,C] (or [n]) rows at int32 `index` [m] -> [m,C]."""
+    cdim = src.shape[1] if src.dim() == 2 else 1
+    m = index.numel()
+    out = torch.empty((m, cdim) if src.dim() == 2 else (m,), dtype=torch.float32, device=src.device)
+    if m > 0:
+        check(load().xmem_gather_rows(ptr(src), cdim, ptr(index), m, ptr(out), stream_ptr()))
+    return out
+
+
+def softmax_rows_suffix(sim, count):
+    P, n = sim.shape
+    check(load().xmem_softmax_rows_suffix(ptr(sim), P, n, count, stream_ptr()))
+    return sim
+
+
+def weighted_rows(aff, count, V):
+    """aff [P,n]; V [count,C] -> [P,C] using the last `count` columns of aff."""
+    P, n = aff.shape
+    cdim = V.shape[1] if V.dim() == 2 else 1
+    out = torch.empty((P, cdim), dtype=torch.float32, device=aff.device)
+    check(load().xmem_weighted_rows(ptr(aff), P, n, count, ptr(V), cdim, ptr(out), stream_ptr()))
+    return out
+
+
+def select_greater(usage, threshold_dev):
+    n = usage.numel()
+    idx = torch.empty((n,), dtype=torch.int32, device=usage.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=usage.device)
+    check(load().xmem_select_greater(ptr(usage), n, ptr(threshold_dev), ptr(idx), ptr(cnt), stream_ptr()))
+    return idx, cnt

@@ -1,0 +1,250 @@
+"""Video harness with the reference's ``run_on_video`` surface (inference/run_on_video.py:31-282).
+
+Frame decoding, mask reading and PNG writing are host I/O outside the timed region of the reference
+(run_on_video.py:106-113) and outside this tier's hot path; this module supplies a minimal reader/writer
+(PIL only - torchvision / cv2 are not available) so that the drop-in call works end to end:
+
+    stats = run_on_video(imgs_in_path, masks_in_path, masks_out_path, frames_with_masks=[0, 10])
+
+What is reproduced from the reference: config merge and the derived ``enable_long_term_count_usage``
+(:190-196), preload of all annotated frames into permanent memory before the loop (:59-66), the per-frame
+``step`` call and its flags (:98-108), resize + argmax post-processing (:165-173, on the GPU), the stats rows
+(:115-123) and the output layout ``<out>/masks/<frame>.png`` (+ ``overlay/<frame>.jpg``).
+Not reproduced: mp4 extraction (needs cv2), deterministic augmentations.
+"""
+import os
+import queue
+import threading
+from dataclasses import dataclass
+from time import perf_counter
+from typing import Iterable, Optional
+from warnings import warn
+
+import numpy as np
+import torch
+
+from . import ops
+from .configuration import VIDEO_INFERENCE_CONFIG
+from .inference_core import InferenceCore
+from .mask_mapper import MaskMapper
+from .network import XMem
+from .tensor_util import compute_array_iou
+
+IM_MEAN = np.array([0.485, 0.456, 0.406], np.float32)     # dataset/range_transform.py:5-8
+IM_STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+@dataclass
+class Sample:
+    rgb: torch.Tensor
+    raw_image_pil: object
+    frame: str
+    save: bool
+    shape: tuple
+    need_resize: bool
+    mask: Optional[np.ndarray] = None
+
+
+class VideoReader:
+    """Directory-of-frames reader (inference/data/video_reader.py:31-118 without cv2 / torchvision)."""
+
+    def __init__(self, vid_name, video_path, mask_dir, size=-1, use_all_masks=False):
+        from PIL import Image
+        self._Image = Image
+        if os.path.isfile(video_path):
+            raise NotImplementedError('video files need cv2 for frame extraction; pass a directory of frames')
+        self.vid_name, self.image_dir, self.mask_dir = vid_name, video_path, mask_dir
+        self.size, self.use_all_masks = size, use_all_masks
+        self.frames = sorted(os.listdir(self.image_dir))
+        masks = sorted(os.listdir(mask_dir))
+        self.first_gt_path = os.path.join(mask_dir, masks[0])
+        self.reference_mask = Image.open(self.first_gt_path).convert('P')
+
+    def __len__(self):
+        return len(self.frames)
+
+    def _target_hw(self, h, w):
+        if self.size < 0:
+            return h, w
+        s = self.size / min(h, w)                  # Resize(size): shorter side -> size
+        return (self.size, int(w * s)) if h <= w else (int(h * s), self.size)
+
+    def __getitem__(self, idx) -> Sample:
+        Image = self._Image
+        name = self.frames[idx]
+        img = Image.open(os.path.join(self.image_dir, name)).convert('RGB')
+        shape = (img.size[1], img.size[0])
+        th, tw = self._target_hw(*shape)
+        work = img if (th, tw) == shape else img.resize((tw, th), Image.BILINEAR)
+        arr = (np.asarray(work, np.float32) / 255.0 - IM_MEAN) / IM_STD
+        rgb = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+        gt_path = os.path.join(self.mask_dir, name[:-4] + '.png')
+        if not os.path.exists(gt_path):
+            gt_path = os.path.join(self.mask_dir, name[:-4] + '.PNG')
+        mask = None
+        if (self.use_all_masks or gt_path == self.first_gt_path) and os.path.exists(gt_path):
+            mask = np.array(Image.open(gt_path).convert('P'), dtype=np.uint8)
+        return Sample(rgb=rgb, raw_image_pil=img, frame=name, save=True, shape=shape,
+                      need_resize=not (self.size < 0), mask=mask)
+
+    def resize_mask(self, onehot):
+        """nearest resize of a [K,H,W] one-hot mask to the working size (video_reader.py:148-153)."""
+        h, w = onehot.shape[-2:]
+        m = min(h, w)
+        th, tw = int(h / m * self.size), int(w / m * self.size)
+        if (th, tw) == (h, w):
+            return onehot
+        ys = (np.arange(th) * (h / th)).astype(np.int64)
+        xs = (np.arange(tw) * (w / tw)).astype(np.int64)
+        return onehot[:, torch.from_numpy(ys)][:, :, torch.from_numpy(xs)]
+
+    def map_the_colors_back(self, pred_mask):
+        Image = self._Image
+        return pred_mask.quantize(palette=self.reference_mask, dither=Image.Dither.NONE).convert('RGB')
+
+
+class _AsyncSaver:
+    """One background thread writing masks / overlays (the reference uses two processes, util/image_saver.py:240-345)."""
+
+    def __init__(self, out_dir, vid_name, max_queue=200):
+        self.root = os.path.join(out_dir, vid_name)
+        self.q = queue.Queue(max_queue)
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            img, sub, name = job
+            d = os.path.join(self.root, sub)
+            os.makedirs(d, exist_ok=True)
+            img.save(os.path.join(d, name))
+
+    def save(self, img, sub, name):
+        self.q.put((img, sub, name))
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+
+
+def _overlay(img, mask_rgb, alpha=0.5):
+    from PIL import Image
+    m = np.asarray(mask_rgb.resize(img.size, Image.NEAREST) if mask_rgb.size != img.size else mask_rgb)
+    fg = m.sum(-1) > 0
+    a = np.full(m.shape[:2], 255, np.uint8)
+    a[fg] = int(alpha * 255)
+    return Image.composite(img, Image.fromarray(m), Image.fromarray(a, mode='L'))
+
+
+def _post_process(sample, prob):
+    """run_on_video.py:165-173: resize to the original shape if needed, argmax over classes, uint8 on the host."""
+    if sample.need_resize and tuple(prob.shape[-2:]) != tuple(sample.shape):
+        prob = ops.resize_bilinear(prob, sample.shape)
+    return ops.argmax_u8(prob).cpu().numpy()
+
+
+def _load_main_objects(imgs_in_path, masks_in_path, config, device):
+    model_path = config['model']
+    network = XMem(config, model_path, pretrained_key_encoder=False, pretrained_value_encoder=False).to(device).eval()
+    if model_path is None:
+        warn('No model weights were loaded, as config["model"] was not specified.')
+    vid_reader = VideoReader('', imgs_in_path, masks_in_path, size=config['size'], use_all_masks=True)
+    vid_length = len(vid_reader)
+    config['enable_long_term_count_usage'] = (                       # run_on_video.py:190-196
+        config['enable_long_term'] and
+        (vid_length / (config['max_mid_term_frames'] - config['min_mid_term_frames']) * config['num_prototypes'])
+        >= config['max_long_term_elements'])
+    return MaskMapper(), InferenceCore(network, config=config), vid_reader
+
+
+def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_out_path, original_memory_mechanism=False,
+                        compute_iou=False, manually_curated_masks=False, print_progress=True,
+                        augment_images_with_masks=False, overwrite_config: dict = None, save_overlay=True,
+                        object_color_if_single_object=(255, 255, 255), print_fps=False, image_saving_max_queue_size=200):
+    import pandas as pd
+    from PIL import Image
+    if not torch.cuda.is_available():
+        raise RuntimeError('xmem2_amd.run_on_video needs an MI355X (HIP) device - there is no CPU path')
+    if augment_images_with_masks:
+        raise NotImplementedError('deterministic augmentations are not part of this tier (SURVEY.md 8f)')
+    device = torch.device('cuda', torch.cuda.current_device())
+    torch.autograd.set_grad_enabled(False)
+    frames_with_masks = set(frames_with_masks)
+    config = VIDEO_INFERENCE_CONFIG.copy()
+    overwrite_config = {} if overwrite_config is None else overwrite_config
+    overwrite_config['masks_out_path'] = masks_out_path
+    config.update(overwrite_config)
+    mapper, processor, vid_reader = _load_main_objects(imgs_in_path, masks_in_path, config, device)
+    vid_length = len(vid_reader)
+
+    to_permanent = [0] if original_memory_mechanism else sorted(frames_with_masks)
+    loaded, preload_time = False, 0.0
+    for j in to_permanent:                                           # _preload_permanent_memory, :201-244
+        sample = vid_reader[j]
+        if sample.mask is None:
+            raise FileNotFoundError(f"Couldn't find mask {j}! Check that the filename is the same as for frame {j}.")
+        msk, _ = mapper.convert_mask(sample.mask, exhaustive=True)
+        if min(msk.shape) == 0:
+            warn(f'Skipping adding frame {j} to permanent memory, as the mask is empty')
+            continue
+        if sample.need_resize:
+            msk = vid_reader.resize_mask(msk)
+        processor.set_all_labels(list(mapper.remappings.values()))
+        a = perf_counter()
+        processor.put_to_permanent_memory(sample.rgb.to(device), msk.to(device))
+        torch.cuda.synchronize()
+        preload_time += perf_counter() - a
+        loaded = True
+    if not loaded:
+        raise ValueError('No valid masks provided!')
+
+    stats, total_time = [], 0.0
+    saver = _AsyncSaver(config['masks_out_path'], vid_reader.vid_name, image_saving_max_queue_size) if config['save_masks'] else None
+    try:
+        for ti in range(vid_length):
+            sample = vid_reader[ti]
+            rgb = sample.rgb.to(device)
+            msk = labels = None
+            if ti in frames_with_masks and sample.mask is not None:
+                msk, labels = mapper.convert_mask(sample.mask, exhaustive=True)
+                if sample.need_resize:
+                    msk = vid_reader.resize_mask(msk)
+                msk = msk.to(device)
+                processor.set_all_labels(list(mapper.remappings.values()))
+            skip_add = (ti == 0) if original_memory_mechanism else (msk is not None)
+            a = perf_counter()
+            prob = processor.step(rgb, msk, labels, end=(ti == vid_length - 1),
+                                  manually_curated_masks=manually_curated_masks, do_not_add_mask_to_memory=skip_add)
+            out_mask = _post_process(sample, prob)                   # .cpu() synchronises the stream
+            total_time += perf_counter() - a
+            stat = {'frame': sample.frame, 'mask_provided': msk is not None}
+            if compute_iou:
+                gt = sample.mask
+                stat['iou'] = float(compute_array_iou(out_mask, gt)) if (gt is not None and msk is None) else -1
+            stats.append(stat)
+            if saver is not None:
+                out_img = vid_reader.map_the_colors_back(Image.fromarray(mapper.remap_index_mask(out_mask)))
+                saver.save(out_img, 'masks', sample.frame[:-4] + '.png')
+                if save_overlay:
+                    saver.save(_overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg')
+    finally:
+        if saver is not None:
+            saver.close()
+    if print_fps:
+        print(f'TOTAL PRELOADING TIME: {preload_time:.4f}s')
+        print(f'TOTAL PROCESSING TIME: {total_time:.4f}s')
+        print(f'TOTAL PROCESSING FPS: {vid_length / total_time:.4f}')
+        print(f'TOTAL FPS (excluding image saving): {vid_length / (preload_time + total_time):.4f}')
+    return pd.DataFrame(stats)
+
+
+def run_on_video(imgs_in_path, masks_in_path, masks_out_path, frames_with_masks: Iterable[int] = (0,),
+                 compute_iou=False, print_progress=True, **kwargs):
+    """Same signature / return as inference/run_on_video.py:247-282: per-frame stats DataFrame
+    (frame, mask_provided[, iou]); predicted masks are written under ``masks_out_path/masks``."""
+    return _inference_on_video(imgs_in_path=imgs_in_path, masks_in_path=masks_in_path, masks_out_path=masks_out_path,
+                               frames_with_masks=frames_with_masks, compute_iou=compute_iou,
+                               print_progress=print_progress, **kwargs)
