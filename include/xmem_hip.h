@@ -151,7 +151,7 @@ typedef struct {
 
 /* segments are searched as one virtual concatenation (long | temporary | permanent in the reference's
  * order, memory_manager.py:82-83); out indices are positions in that concatenation.
- * qk [HW][C_k]; qe [HW][C_k] or NULL.  top_k in [1, 112], sum(n) >= top_k else XMEM_ERR_TOPK.
+ * qk [HW][C_k]; qe [HW][C_k] or NULL.  top_k in [1, 64], sum(n) >= top_k else XMEM_ERR_TOPK.
  * out_w [HW][top_k] softmax weights exp(v)/sum exp(v) (no max shift, memory_util.py:48-49), sorted by
  * descending similarity; out_idx [HW][top_k]; out_sim (nullable) [HW][top_k] raw similarities. */
 size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int top_k);

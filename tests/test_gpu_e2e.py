@@ -1,0 +1,90 @@
+"""GPU parity (end to end): InferenceCore.step over the synthetic clips recorded from the imported reference.
+
+Acceptance: IoU >= 0.999 per clip against the reference's argmax masks and argmax identical wherever
+the reference's own top-2 probability margin exceeds its thread-noise floor."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _run_clip(hip_net, tag, hw, n_obj):
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    g = load_golden('e2e_' + tag)
+    cfg = ast.literal_eval(str(g['config']))
+    t = int(g['shape'][0])
+    frames = T(synthetic_frames(t, *hw)).cuda(); masks = T(synthetic_masks(t, n_obj, *hw)).cuda()
+    labels = [int(x) for x in g['labels']]
+    core = InferenceCore(hip_net, cfg)
+    core.set_all_labels(labels)
+    for j in g['perm_frames']:
+        core.put_to_permanent_memory(frames[int(j)], masks[int(j)])
+    mask_frames = set(int(x) for x in g['mask_frames'])
+    out, sizes, probs = [], [], []
+    for ti in range(t):
+        mk = masks[ti] if ti in mask_frames else None
+        p = core.step(frames[ti], mk, labels if mk is not None else None, end=(ti == t - 1),
+                      do_not_add_mask_to_memory=(mk is not None))
+        assert p.shape == (n_obj + 1,) + tuple(hw)
+        out.append(ops.argmax_u8(p).cpu().numpy())
+        probs.append(p[:, 4::8, 4::8].cpu().numpy())
+        m = core.memory
+        sizes.append([m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size])
+    return np.stack(out), np.array(sizes), np.stack(probs), g
+
+
+@pytest.mark.parametrize('tag,hw,n_obj', [('480p_1obj', (480, 854), 1), ('240p_2obj', (240, 427), 2)])
+def test_e2e_clip(hip_net, tag, hw, n_obj):
+    got, sizes, probs, g = _run_clip(hip_net, tag, hw, n_obj)
+    ref = g['argmax']
+    np.testing.assert_array_equal(sizes, g['sizes'])
+    ious = [R.compute_array_iou(got[i], ref[i]) for i in range(len(ref))]
+    mism = float((got != ref).mean())
+    d = np.abs(probs - g['prob_ds8'])
+    print(f'{tag}: min IoU {min(ious):.5f}, argmax mismatch {mism:.2e}, prob max err {d.max():.3e} mean {d.mean():.3e}')
+    # clip-level IoU per object (the reference's own 8-thread vs 1-thread runs reach only 0.998 on single frames of
+    # this clip because object 1 is ~1800 px: a handful of boundary pixels; see DESIGN.md "noise floor")
+    labels = [int(x) for x in g['labels']]
+    clip_iou = [((got == c) & (ref == c)).sum() / max(((got == c) | (ref == c)).sum(), 1) for c in labels]
+    print(f'{tag}: clip IoU per object {clip_iou}')
+    assert min(clip_iou) >= 0.999, f'{tag}: clip-level IoU {clip_iou} < 0.999'
+    assert min(ious) >= 0.99, f'{tag}: per-frame IoU {min(ious):.5f} < 0.99 (frame {int(np.argmin(ious))})'
+    assert mism < 1e-4, f'{tag}: argmax mismatch fraction {mism:.2e}'
+    # argmax identical wherever the reference's top-2 margin is clear (sampled grid where probabilities are stored)
+    pr = g['prob_ds8']
+    srt = np.sort(pr, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    clear = margin > 5e-2
+    assert np.array_equal(probs.argmax(1)[clear], pr.argmax(1)[clear]), 'argmax differs where the reference margin is clear'
+    assert d.mean() < 5e-4, f'mean prob error {d.mean():.3e}'
+
+
+def test_step_flags_and_key_outputs(hip_net):
+    """return_key_and_stuff shapes, disable_memory_updates, valid_labels merge path, 2 objects."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    fr = T(synthetic_frames(3, 96, 130)).cuda(); mk = T(synthetic_masks(3, 2, 96, 130)).cuda()
+    core = InferenceCore(hip_net, base_config(mem_every=1))
+    core.set_all_labels([1, 2])
+    core.put_to_permanent_memory(fr[0], mk[0])
+    ti0 = core.curr_ti
+    p, key, shr, sel = core.step(fr[1], None, None, disable_memory_updates=True, return_key_and_stuff=True)
+    assert core.curr_ti == ti0 and core.memory.temporary_work_mem.size == 0
+    assert p.shape == (3, 96, 130) and key.shape == (1, 64, 6, 9) and shr.shape == (1, 1, 6, 9) and sel.shape == (1, 64, 6, 9)
+    k2, s2, e2 = core.encode_frame_key(fr[1])
+    assert torch.allclose(k2, key) and torch.allclose(s2, shr) and torch.allclose(e2, sel)
+    # a mask for object 1 only: object 2 keeps the prediction outside the given region
+    p2 = core.step(fr[2], mk[2], [1])
+    assert p2.shape == (3, 96, 130) and bool(torch.isfinite(p2).all())
+    assert float((p2.sum(0) - 1).abs().max()) < 1e-5
+    assert core.memory.temporary_work_mem.size == 6 * 9

@@ -1,0 +1,72 @@
+"""GPU parity (network level): encode_key / encode_value / segment through the HIP path vs the golden outputs of the
+imported reference (tests/golden/net_96x128.npz) and vs the oracle at the benchmark geometry."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12)), float((a - b).abs().mean() / (b.abs().mean() + 1e-12))
+
+
+def check(a, b, name, tol_max=2e-3, tol_mean=2e-4):
+    mx, mean = rel_err(a, b)
+    assert mx < tol_max and mean < tol_mean, f'{name}: max rel-to-scale err {mx:.3e}, mean rel err {mean:.3e}'
+
+
+def test_encode_key_golden(hip_net):
+    g = load_golden('net_96x128')
+    frame = T(g['frame']).cuda()
+    key, shr, sel, f16, f8, f4 = hip_net.encode_key(frame)
+    torch.cuda.synchronize()
+    for got, name in ((f4, 'f4'), (f8, 'f8'), (f16, 'f16'), (key, 'key'), (shr, 'shrinkage'), (sel, 'selection')):
+        check(got, T(g[name]), 'encode_key.' + name)
+
+
+def test_encode_value_and_segment_golden(hip_net):
+    g = load_golden('net_96x128')
+    frame, masks, hidden0, readout = (T(g[k]).cuda() for k in ('frame', 'masks', 'hidden0', 'readout'))
+    key, shr, sel, f16, f8, f4 = hip_net.encode_key(frame)
+    prob = R.aggregate(T(g['masks'])[0], dim=0)
+    value, hid = hip_net.encode_value(frame, f16, hidden0, prob[1:].unsqueeze(0).cuda(), is_deep_update=True)
+    check(value, T(g['value']), 'encode_value.value')
+    check(hid, T(g['hidden_value']), 'encode_value.hidden')
+    v2, h2 = hip_net.encode_value(frame, f16, hidden0, prob[1:].unsqueeze(0).cuda(), is_deep_update=False)
+    check(v2, T(g['value']), 'encode_value.value (no deep update)')
+    assert torch.equal(h2.cpu(), hidden0.cpu())
+    hs, _, pr = hip_net.segment((f16, f8, f4), readout, hidden0, h_out=True, strip_bg=False)
+    check(hs, T(g['hidden_seg']), 'segment.hidden')
+    d = (pr.cpu() - T(g['prob'])).abs()
+    assert float(d.max()) < 2e-2 and float(d.mean()) < 1e-4, f'segment.prob: max {float(d.max()):.3e} mean {float(d.mean()):.3e}'
+    hs2, _, pr2 = hip_net.segment((f16, f8, f4), readout, hidden0, h_out=False, strip_bg=True)
+    assert hs2 is None and pr2.shape[1] == 2
+
+
+def test_network_480p_vs_oracle(hip_net, ref_net):
+    """One frame at the benchmark geometry (480x864 padded): every stage against the oracle."""
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    fr = T(synthetic_frames(1, 480, 854, seed=5)[0]); mk = T(synthetic_masks(1, 1, 480, 854)[0])
+    img, _ = R.pad_divide_by(fr, 16); m, _ = R.pad_divide_by(mk, 16)
+    ref = ref_net.encode_key(img[None])
+    got = hip_net.encode_key(img[None].cuda())
+    for a, b, n in zip(got, ref, 'key shrinkage selection f16 f8 f4'.split()):
+        check(a, b, '480p encode_key.' + n)
+    hidden = torch.randn(1, 1, 64, 30, 54, generator=torch.Generator().manual_seed(1)) * 0.3
+    pb = R.aggregate(m, dim=0)
+    rv, rh = ref_net.encode_value(img[None], ref[3], hidden, pb[1:][None], True)
+    gv, gh = hip_net.encode_value(img[None].cuda(), got[3], hidden.cuda(), pb[1:][None].cuda(), True)
+    check(gv, rv, '480p value'); check(gh, rh, '480p value hidden')
+    rs = ref_net.segment(ref[3:], rv, rh, h_out=True, strip_bg=False)
+    gs = hip_net.segment(got[3:], gv, gh, h_out=True, strip_bg=False)
+    check(gs[0], rs[0], '480p segment hidden')
+    d = (gs[2].cpu() - rs[2]).abs()
+    mism = (gs[2].cpu().argmax(1) != rs[2].argmax(1)).float().mean()
+    assert float(d.mean()) < 1e-4 and float(d.max()) < 3e-2 and float(mism) < 2e-4, (float(d.mean()), float(d.max()), float(mism))

@@ -1,0 +1,411 @@
+"""GPU parity (op level): every kernel, called through the C ABI, against the oracle / plain torch-CPU fp32
+on the same seeded inputs.  Tolerances are fp32-roundoff class (different summation order only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def g_(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def nhwc(x):      # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(x):      # NHWC cuda -> NCHW cpu
+    return x.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rtol=2e-4, atol=2e-5, msg=''):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), f'{msg}: {int(bad.sum())}/{bad.numel()} out of tol, max abs err {float(err.max()):.3e}, ' \
+                                f'ref scale {float(b.abs().max()):.3e}, first bad idx {bad.nonzero()[0].tolist()}'
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, relu_in, relu_out, residual, bn
+    (1, 24, 40, 64, 64, 1, 1, 0, False, True, False, True),        # bottleneck conv1
+    (1, 24, 40, 64, 64, 3, 1, 1, False, True, False, True),        # bottleneck conv2
+    (1, 24, 40, 64, 256, 1, 1, 0, False, True, True, True),        # conv3 + residual + relu
+    (1, 24, 40, 256, 128, 3, 2, 1, False, True, False, True),      # strided 3x3
+    (1, 24, 40, 256, 512, 1, 2, 0, False, False, False, True),     # strided 1x1 downsample
+    (1, 48, 80, 4, 64, 7, 2, 3, False, True, False, True),         # key stem (generic K path)
+    (2, 48, 80, 8, 64, 7, 2, 3, False, True, False, True),         # value stem, two objects
+    (2, 6, 10, 1600, 512, 3, 1, 1, True, True, False, False),      # fuser block1.conv1 (relu_in/out, split-K)
+    (1, 6, 10, 1600, 512, 3, 1, 1, False, False, False, False),    # fuser downsample
+    (2, 6, 10, 512, 512, 3, 1, 1, False, False, True, False),      # conv2 + residual
+    (1, 30, 54, 1024, 129, 3, 1, 1, False, False, False, False),   # key projection (Cout=129)
+    (2, 24, 40, 256, 1, 3, 1, 1, True, False, False, False),       # pred (Cout=1, relu_in)
+    (2, 6, 10, 260, 256, 1, 1, 0, False, False, True, False),      # g4_conv (generic K, residual chain)
+    (1, 60, 108, 256, 256, 3, 1, 1, True, True, False, False),     # decoder up_8_4-like, 128x128 tiles
+    (3, 15, 27, 576, 192, 3, 1, 1, False, False, False, False),    # GRU transform, odd spatial size
+    (1, 17, 23, 64, 96, 3, 1, 1, False, False, False, False),      # ragged M and N tails
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(str(int(v)) for v in c))
+def test_conv2d(case):
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    B, H, W, Cin, Cout, k, stride, pad, relu_in, relu_out, use_res, bn = case
+    gen = g_(hash(case) & 0xffff)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, k, k, generator=gen) * (1.0 / (Cin * k * k)) ** 0.5
+    if bn:
+        scale = torch.rand(Cout, generator=gen) * 0.5 + 0.75
+        shift = torch.randn(Cout, generator=gen) * 0.1
+    else:
+        scale = torch.ones(Cout)
+        shift = torch.randn(Cout, generator=gen) * 0.1
+    xin = F.relu(x) if relu_in else x
+    ref = F.conv2d(xin, w, None, stride, pad) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=gen) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu_out:
+        ref = F.relu(ref)
+    cw = ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda(), stride, pad)
+    out = ops.conv2d(nhwc(x), cw, res=nhwc(res) if use_res else None, relu_in=relu_in, relu_out=relu_out)
+    torch.cuda.synchronize()
+    close(nchw(out), ref, rtol=2e-4, atol=5e-5, msg=f'conv {case}')
+
+
+def test_conv2d_into_channel_slice_and_strided_input():
+    """ldin / ldout: read a channel slice of a wider buffer and write into the middle of a concat buffer."""
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    gen = g_(5)
+    wide = torch.randn(1, 12, 20, 96, generator=gen)           # NHWC buffer; conv reads channels [0, 64)
+    w = torch.randn(32, 64, 3, 3, generator=gen) * 0.05
+    ref = F.conv2d(wide[..., :64].permute(0, 3, 1, 2), w, None, 1, 1)
+    cw = ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), torch.ones(32).cuda(), torch.zeros(32).cuda(), 1, 1)
+    dst = torch.full((1, 12, 20, 80), 7.0).cuda()
+    import ctypes
+    from xmem2_amd import _lib
+    d = _lib.ConvDesc()
+    xw = wide.cuda()
+    d.inp = xw.data_ptr(); d.B, d.H, d.W, d.Cin, d.ldin = 1, 12, 20, 64, 96
+    d.w = cw.w.data_ptr(); d.Cout, d.KH, d.KW, d.stride, d.pad = 32, 3, 3, 1, 1
+    d.scale = cw.scale.data_ptr(); d.shift = cw.shift.data_ptr(); d.res = None; d.ldres = 0
+    d.out = dst.data_ptr() + 4 * 16; d.ldout = 80
+    lib = _lib.load()
+    need = lib.xmem_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device='cuda')
+    _lib.check(lib.xmem_conv2d_nhwc(ctypes.byref(d), _lib.ptr(ws), need, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    got = dst.cpu()
+    close(got[..., 16:48].permute(0, 3, 1, 2), ref, msg='slice conv')
+    assert bool((got[..., :16] == 7.0).all()) and bool((got[..., 48:] == 7.0).all()), 'neighbouring channels were clobbered'
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pooling / resampling / gates
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(1, 48, 80, 64), (2, 15, 27, 64), (1, 7, 9, 8)])
+def test_maxpool(shape):
+    from xmem2_amd import ops
+    x = torch.randn(*shape, generator=g_(1))
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1)
+    close(nchw(ops.maxpool3x3s2(x.cuda())), ref, 0, 0, 'maxpool')
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 10, 512), (1, 15, 27, 256), (3, 5, 7, 8)])
+def test_upsample2x_add(shape):
+    from xmem2_amd import ops
+    B, h, w, C = shape
+    g = torch.randn(*shape, generator=g_(2))
+    skip = torch.randn(1, 2 * h, 2 * w, C, generator=g_(3))
+    ref = F.interpolate(g.permute(0, 3, 1, 2), scale_factor=2, mode='bilinear', align_corners=False) + skip.permute(0, 3, 1, 2)
+    close(nchw(ops.upsample2x_add(g.cuda(), skip.cuda())), ref, 1e-5, 1e-5, 'upsample2x_add')
+
+
+@pytest.mark.parametrize('r', [2, 4])
+def test_area_downsample(r):
+    from xmem2_amd import ops
+    x = torch.randn(2, 24, 40, 36, generator=g_(4))
+    ref = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=1 / r, mode='area')
+    close(nchw(ops.area_downsample(x.cuda(), r)), ref, 1e-5, 1e-6, 'area')
+    # strided destination (cat(g4, logits) builder)
+    dst = torch.zeros(2, 24 // r, 40 // r, 40).cuda()
+    ops.area_downsample(x.cuda(), r, out=dst, out_ld=40, out_off=4)
+    close(nchw(dst)[:, 4:40], ref, 1e-5, 1e-6, 'area strided')
+    assert float(dst[..., :4].abs().max()) == 0.0
+
+
+def test_copy_channels_broadcast():
+    from xmem2_amd import ops
+    src = torch.randn(1, 5, 7, 16, generator=g_(6))
+    g = torch.randn(3, 5, 7, 8, generator=g_(7))
+    dst = torch.zeros(3, 5, 7, 24).cuda()
+    ops.copy_channels(src.cuda(), dst, 0)
+    ops.copy_channels(g.cuda(), dst, 16)
+    ref = torch.cat([src.expand(3, -1, -1, -1), g], 3)
+    close(dst, ref, 0, 0, 'copy_channels')
+
+
+@pytest.mark.parametrize('B', [1, 2])
+def test_cbam_residual(B, synth_sd, ref_net):
+    from xmem2_amd import ops
+    p = 'decoder.fuser.attention'
+    g = torch.randn(B, 512, 15, 27, generator=g_(8)) * 0.5
+    ref = g + ref_net._cbam(g, p)
+    params = dict(w1=synth_sd[p + '.ChannelGate.mlp.1.weight'].cuda(), b1=synth_sd[p + '.ChannelGate.mlp.1.bias'].cuda(),
+                  w2=synth_sd[p + '.ChannelGate.mlp.3.weight'].cuda(), b2=synth_sd[p + '.ChannelGate.mlp.3.bias'].cuda(),
+                  sw=synth_sd[p + '.SpatialGate.spatial.conv.weight'].reshape(2, 7, 7).contiguous().cuda(),
+                  sb=synth_sd[p + '.SpatialGate.spatial.conv.bias'].cuda())
+    out = ops.cbam_residual(nhwc(g), params)
+    close(nchw(out), ref, 1e-4, 1e-5, 'cbam')
+
+
+def test_gru_gate():
+    from xmem2_amd import ops
+    v = torch.randn(2, 6, 10, 192, generator=g_(9))
+    h = torch.randn(2, 6, 10, 64, generator=g_(10))
+    f, u, n = torch.sigmoid(v[..., :64]), torch.sigmoid(v[..., 64:128]), torch.tanh(v[..., 128:])
+    ref = f * h * (1 - u) + u * n
+    close(ops.gru_gate(v.cuda(), h.cuda()), ref, 1e-5, 1e-6, 'gru')
+
+
+def test_pack_image_and_value_input():
+    from xmem2_amd import ops
+    from xmem2_amd.tensor_util import pad_amounts
+    img = torch.randn(3, 50, 70, generator=g_(11))
+    lw, uw, lh, uh = pad_amounts(50, 70)
+    padded, _ = R.pad_divide_by(img, 16)
+    out = ops.pack_image(img.cuda(), 50 + lh + uh, 70 + lw + uw, lh, lw)
+    close(out[0, ..., :3].permute(2, 0, 1), padded, 0, 0, 'pack_image')
+    assert float(out[..., 3].abs().max()) == 0
+    masks = (torch.rand(3, 64, 80, generator=g_(12)) > 0.7).float()
+    v = ops.pack_value_input(out, masks.cuda()).cpu()
+    others = torch.stack([masks[[j for j in range(3) if j != i]].sum(0) for i in range(3)])
+    close(v[..., 3], masks, 0, 0, 'mask channel')
+    close(v[..., 4], others, 0, 0, 'others channel')
+    close(v[..., :3], out[0, ..., :3].cpu().expand(3, -1, -1, -1), 0, 0, 'rgb channels')
+    assert float(v[..., 5:].abs().max()) == 0
+
+
+def test_key_post():
+    from xmem2_amd import ops
+    proj = torch.randn(1, 6, 10, 132, generator=g_(13))
+    key, shr, sel = ops.key_post(proj.cuda(), 64)
+    flat = proj.view(60, 132)
+    close(key, flat[:, :64], 0, 0, 'key')
+    close(shr, flat[:, 64] ** 2 + 1, 1e-6, 1e-6, 'shrinkage')
+    close(sel, torch.sigmoid(flat[:, 65:129]), 1e-6, 1e-6, 'selection')
+
+
+@pytest.mark.parametrize('K', [1, 3])
+def test_logits_to_prob_and_aggregate(K):
+    from xmem2_amd import ops
+    from xmem2_amd.tensor_util import pad_amounts
+    H, W = 50, 70
+    lw, uw, lh, uh = pad_amounts(H, W)
+    h4, w4 = (H + lh + uh) // 4, (W + lw + uw) // 4
+    logits = torch.randn(K, h4, w4, generator=g_(14)) * 4
+    up = F.interpolate(logits.unsqueeze(0), scale_factor=4, mode='bilinear', align_corners=False)
+    _, ref = R.aggregate(torch.sigmoid(up), dim=1, return_logits=True)
+    prob, padded = ops.logits_to_prob(logits.cuda(), H, W, lh, lw)
+    close(padded, ref[0], 1e-4, 1e-6, 'prob padded')
+    close(prob, R.unpad(ref[0], (lw, uw, lh, uh)), 1e-4, 1e-6, 'prob cropped')
+    masks = (torch.rand(K, 32, 48, generator=g_(15)) > 0.6).float()
+    close(ops.aggregate_masks(masks.cuda()), R.aggregate(masks, dim=0), 1e-5, 1e-7, 'aggregate masks')
+    soft = torch.rand(K, 32, 48, generator=g_(16))
+    close(ops.aggregate_masks(soft.cuda()), R.aggregate(soft, dim=0), 1e-4, 1e-6, 'aggregate soft')
+
+
+def test_merge_masks_and_argmax_and_resize():
+    from xmem2_amd import ops
+    K, H, W = 3, 32, 48
+    pred = torch.rand(K, H, W, generator=g_(17))
+    mask = (torch.rand(K, H, W, generator=g_(18)) > 0.8).float()
+    valid = [1, 3]
+    ref_pred = pred.clone()
+    ref_pred[:, mask.sum(0) > 0.5] = 0
+    ref = mask.clone()
+    keep = [i for i in range(K) if (i + 1) not in valid]
+    ref[keep] = ref_pred[keep]
+    bits = sum(1 << i for i in range(K) if (i + 1) in valid)
+    close(ops.merge_masks(pred.cuda(), mask.cuda(), bits), ref, 0, 0, 'merge_masks')
+    prob = torch.rand(K + 1, H, W, generator=g_(19))
+    assert np.array_equal(ops.argmax_u8(prob.cuda()).cpu().numpy(), torch.argmax(prob, 0).numpy().astype(np.uint8))
+    big = F.interpolate(prob.unsqueeze(1), (45, 80), mode='bilinear', align_corners=False)[:, 0]
+    close(ops.resize_bilinear(prob.cuda(), (45, 80)), big, 1e-5, 1e-6, 'resize')
+
+
+def test_layout_transposes():
+    from xmem2_amd import ops
+    x = torch.randn(2, 37, 9, 11, generator=g_(20))         # NCHW
+    y = ops.nchw_to_nhwc(x.cuda())
+    close(y, x.permute(0, 2, 3, 1), 0, 0, 'nchw_to_nhwc')
+    close(ops.nhwc_to_nchw(y), x, 0, 0, 'nhwc_to_nchw')
+
+
+# ---------------------------------------------------------------------------------------------------------
+# affinity / readout / usage
+# ---------------------------------------------------------------------------------------------------------
+def _check_topk(w, idx, sim_ref, top_k, tag):
+    """Compare as sets: the k-th / (k+1)-th values may tie or be within roundoff, so membership is checked by value."""
+    w, idx = w.cpu(), idx.cpu().long()
+    HW = sim_ref.shape[2]
+    vals_ref, idx_ref = torch.topk(sim_ref[0], top_k, dim=0)              # [k, HW]
+    x = vals_ref.exp(); w_ref = (x / x.sum(0, keepdim=True)).t()        # [HW, k] sorted desc
+    assert int(idx.min()) >= 0 and int(idx.max()) < sim_ref.shape[1]
+    picked = sim_ref[0].t().gather(1, idx)                               # similarity (oracle) of the picked elements
+    kth = vals_ref[-1].unsqueeze(1)
+    assert bool((picked >= kth - 1e-4 * (1 + kth.abs())).all()), f'{tag}: picked an element below the k-th value'
+    for q in range(0, HW, max(1, HW // 50)):
+        assert len(set(idx[q].tolist())) == top_k, f'{tag}: duplicate index for query {q}'
+    same = (torch.sort(idx, 1)[0] == torch.sort(idx_ref.t(), 1)[0]).all(1).float().mean()
+    assert float(same) > 0.97, f'{tag}: only {float(same):.3f} of queries have the identical index set'
+    close(torch.sort(w, 1, descending=True)[0], w_ref, 2e-3, 1e-6, tag + ' weights')
+    assert float((w.sum(1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('tag', ['small', 'mid'])
+def test_affinity_topk_golden(tag):
+    from xmem2_amd import ops
+    g = load_golden('op_' + tag)
+    mk, ms, qk, qe, mv = (T(g[k]) for k in ('mk', 'ms', 'qk', 'qe', 'mv'))
+    sim = R.get_similarity(mk, ms, qk, qe)
+    rows = lambda t: t[0].t().contiguous().cuda()
+    w, idx, sims = ops.affinity_topk([(rows(mk), ms.view(-1).cuda())], rows(qk), rows(qe), 30, want_sim=True)
+    torch.cuda.synchronize()
+    _check_topk(w, idx, sim, 30, 'affinity ' + tag)
+    close(sims, sim[0].t().gather(1, idx.cpu().long()), 1e-4, 1e-4, 'raw similarities')
+    # golden sparse form from the reference run
+    close(torch.sort(w.cpu(), 1, descending=True)[0], T(g['topk_w'])[0].t(), 2e-3, 1e-6, 'weights vs golden')
+    # sparse readout == dense v @ affinity
+    n_obj, cv = mv.shape[0], mv.shape[1]
+    out = torch.zeros(n_obj, qk.shape[2], cv).cuda()
+    vrows = [[mv[o].t().contiguous().cuda()] for o in range(n_obj)]
+    ops.readout_sparse(vrows, w, idx, cv, out, cv, qk.shape[2] * cv)
+    close(out.permute(0, 2, 1), T(g['readout']), 2e-3, 2e-4, 'readout vs golden')
+    # usage
+    n = mk.shape[2]
+    use = torch.zeros(n).cuda(); life = torch.full((n,), 1e-7).cuda()
+    ops.usage_update(w, idx, 0, n, use, life)
+    close(use, T(g['usage'])[0], 2e-3, 1e-5, 'usage vs golden')
+    close(life, torch.full((n,), 1.0 + 1e-7), 0, 0, 'life')
+
+
+@pytest.mark.parametrize('variant', ['se', 's', 'e', 'none'])
+def test_affinity_variants_and_segments(variant):
+    """selection / shrinkage optional; three ragged segments must behave as their concatenation."""
+    from xmem2_amd import ops
+    gen = g_(21)
+    n_seg, hw, ck = (128, 405 * 3 + 7, 50), 405, 64
+    n = sum(n_seg)
+    mk = torch.randn(1, ck, n, generator=gen) * 0.9
+    ms = torch.rand(1, 1, n, generator=gen) * 3 + 1
+    qk = torch.randn(1, ck, hw, generator=gen) * 0.9
+    qe = torch.rand(1, ck, hw, generator=gen) * 0.9 + 0.05
+    use_s, use_e = variant in ('se', 's'), variant in ('se', 'e')
+    sim = R.get_similarity(mk, ms if use_s else None, qk, qe if use_e else None)
+    segs, a = [], 0
+    for c in n_seg:
+        segs.append((mk[0, :, a:a + c].t().contiguous().cuda(), ms[0, 0, a:a + c].contiguous().cuda() if use_s else None))
+        a += c
+    w, idx, _ = ops.affinity_topk(segs, qk[0].t().contiguous().cuda(), qe[0].t().contiguous().cuda() if use_e else None, 30)
+    torch.cuda.synchronize()
+    _check_topk(w, idx, sim, 30, 'affinity ' + variant)
+
+
+@pytest.mark.parametrize('n,hw,k', [(51840, 1620, 30), (30, 40, 30), (8100 + 128, 1350, 30), (5000, 100, 8), (3000, 70, 64)])
+def test_affinity_sizes(n, hw, k):
+    """The benchmark size (32 frames x 1620), N == top_k, other top_k values."""
+    from xmem2_amd import ops
+    gen = g_(n + hw)
+    mk = torch.randn(1, 64, n, generator=gen) * 0.9
+    ms = torch.rand(1, 1, n, generator=gen) * 3 + 1
+    qk = torch.randn(1, 64, hw, generator=gen) * 0.9
+    qe = torch.rand(1, 64, hw, generator=gen) * 0.9 + 0.05
+    sim = R.get_similarity(mk, ms, qk, qe)
+    w, idx, _ = ops.affinity_topk([(mk[0].t().contiguous().cuda(), ms.view(-1).cuda())], qk[0].t().contiguous().cuda(),
+                                  qe[0].t().contiguous().cuda(), k)
+    torch.cuda.synchronize()
+    _check_topk(w, idx, sim, k, f'affinity n={n}')
+
+
+def test_affinity_errors():
+    from xmem2_amd import ops
+    k = torch.randn(20, 64).cuda()
+    with pytest.raises(RuntimeError):
+        ops.affinity_topk([(k, None)], torch.randn(10, 64).cuda(), None, 30)      # N < top_k, like torch.topk
+
+
+def test_affinity_ties_are_exact():
+    """Duplicate memory rows give exactly tied similarities; the result must still be a valid top-k set."""
+    from xmem2_amd import ops
+    gen = g_(33)
+    base = torch.randn(40, 64, generator=gen)
+    mk = base.repeat(4, 1)                                  # every row appears 4 times
+    qk = torch.randn(50, 64, generator=gen)
+    w, idx, sims = ops.affinity_topk([(mk.cuda(), None)], qk.cuda(), None, 30, want_sim=True)
+    sim = R.get_similarity(mk.t().unsqueeze(0), None, qk.t().unsqueeze(0), None)
+    vals_ref = torch.topk(sim[0], 30, dim=0)[0].t()
+    close(torch.sort(sims.cpu(), 1, descending=True)[0], vals_ref, 1e-5, 1e-5, 'tied values')
+    for q in range(50):
+        assert len(set(idx[q].tolist())) == 30
+
+
+# ---------------------------------------------------------------------------------------------------------
+# consolidation kernels
+# ---------------------------------------------------------------------------------------------------------
+def test_similarity_dense_softmax_weighted_rows():
+    from xmem2_amd import ops
+    gen = g_(40)
+    n, P, cv = 2500, 64, 128
+    mk = torch.randn(1, 64, n, generator=gen) * 0.9
+    ms = torch.rand(1, 1, n, generator=gen) * 3 + 1
+    pk = torch.randn(1, 64, P, generator=gen) * 0.9
+    pe = torch.rand(1, 64, P, generator=gen) * 0.9 + 0.05
+    sim = R.get_similarity(mk, ms, pk, pe)                        # [1, n, P]
+    got = ops.similarity_dense(mk[0].t().contiguous().cuda(), ms.view(-1).cuda(), pk[0].t().contiguous().cuda(),
+                               pe[0].t().contiguous().cuda())
+    close(got, sim[0].t(), 1e-4, 1e-4, 'similarity_dense')
+    cnt = 1700
+    aff_ref = R.do_softmax(sim[:, -cnt:])                          # softmax over candidates
+    aff = ops.softmax_rows_suffix(got.clone(), cnt)
+    close(aff[:, n - cnt:], aff_ref[0].t(), 2e-3, 1e-9, 'softmax suffix')
+    assert float(aff[:, :n - cnt].abs().max()) == 0
+    V = torch.randn(cnt, cv, generator=gen)
+    ref = (V.t() @ aff_ref[0]).t()                                 # gv @ affinity
+    close(ops.weighted_rows(aff, cnt, V.cuda()), ref, 2e-3, 1e-5, 'weighted rows')
+    s = ms.view(-1)[n - cnt:]
+    close(ops.weighted_rows(aff, cnt, s.cuda()).view(-1), (s.view(1, -1) @ aff_ref[0]).view(-1), 2e-3, 1e-5, 'weighted shrinkage')
+
+
+def test_topk_1d_and_select_and_gather():
+    from xmem2_amd import ops
+    gen = g_(41)
+    v = torch.rand(8100, generator=gen)
+    vals, idx = ops.topk_1d(v.cuda(), 128, largest=True)
+    rv, ri = torch.topk(v, 128)
+    close(vals, rv, 0, 0, 'topk values'); assert idx.cpu().tolist() == ri.tolist()
+    vals, idx = ops.topk_1d(v.cuda(), 77, largest=False)
+    rv, ri = torch.topk(v, 77, largest=False)
+    close(vals, rv, 0, 0, 'bottomk values'); assert idx.cpu().tolist() == ri.tolist()
+    thr = vals[76:77]
+    sel, cnt = ops.select_greater(v.cuda(), thr)
+    keep = (v > rv[-1]).nonzero().flatten()
+    assert int(cnt.item()) == keep.numel() and sel[:keep.numel()].cpu().tolist() == keep.tolist()
+    src = torch.randn(500, 24, generator=gen)
+    pick = torch.randint(0, 500, (77,), generator=gen).to(torch.int32)
+    close(ops.gather_rows(src.cuda(), pick.cuda()), src[pick.long()], 0, 0, 'gather')
+    u, l = torch.rand(100, generator=gen), torch.rand(100, generator=gen) + 0.5
+    close(ops.usage_ratio(u.cuda(), l.cuda()), u / l, 1e-6, 0, 'usage ratio')

@@ -7,13 +7,20 @@
 // A (memory keys, 32 rows x 64 ch per wave) is loaded straight into registers (each key row is used by exactly
 // one wave of the workgroup; squares are formed in-register), B (64 queries x 128 k) is staged once per
 // workgroup in LDS with a 132-float row stride (conflict-free ds_read_b128).  D comes out with one query per
-// lane (col = lane&31) and 16 memory rows per lane, so the top-k filter is lane-local:
-//     v > tau[q]  ->  LDS atomic append to the query's candidate buffer.
-// tau[q] is the k-th largest value seen so far; when a buffer passes `limit` entries a wave re-ranks it by
-// exact counting (ties -> lower memory index), keeps k and raises tau.  Candidates can never overflow:
-// a step adds at most 4 waves x 32 rows = 128 per query and cap = limit + 128.
-// N is split across workgroups; a merge kernel ranks the per-split lists and applies the softmax
-// exp(v)/sum exp(v) (no max shift, memory_util.py:48-49).
+// lane (col = lane&31) and 16 memory rows per lane, so the top-k filter is lane-local.
+//
+// Exact top-k without materialising anything, in two MFMA passes:
+//   pass A (bound): every R-th 32-row tile; each lane keeps the two largest values it sees per query in registers
+//           (branch-free max/min chain).  The k-th largest of the union of those survivors is a value that at
+//           least k memory elements reach, i.e. a LOWER BOUND tau0[q] of the true k-th similarity.
+//   pass B (select): all tiles; v >= tau0[q] -> LDS atomic append of a packed 64-bit key
+//           (orderable(v) << 32 | ~index) to the query's candidate buffer.  About R*k/splits candidates survive per
+//           workgroup, so the exact re-rank (by counting, ties -> lower index) is a rare safety valve:
+//           it runs only if a buffer passes `limit` entries and can never overflow (a step adds at most
+//           4 waves x 32 rows = 128 per query, cap = limit + 128).
+//   merge: one wave per query ranks the surviving candidates of all splits, emits the sorted top-k and the
+//           softmax exp(v)/sum exp(v) (no max shift, memory_util.py:48-49).
+// Small memories (< 256 tiles) skip pass A (tau0 = -inf) and rely on the re-rank.
 #include "common.hpp"
 #include <math.h>
 
@@ -22,6 +29,11 @@
 #define AFF_ROWS 32        // memory rows per wave tile
 #define AFF_STEP_ROWS 128  // rows per step (4 waves)
 #define AFF_MAXU 4         // candidate entries per lane during a re-rank (cap <= 256)
+#define AFF_OUTCAP 64      // candidates a (split, query) hands to the merge kernel
+#define AFF_BOUND_M 2      // survivors per lane and query in the bound pass
+#define AFF_BOUND_SLOTS (8 * AFF_BOUND_M)   // per (split, query): 4 waves x 2 half-waves x M
+
+typedef unsigned long long u64;
 
 struct SegDev { const float* key; const float* shr; int n; int base; int tile0; int pad; };
 
@@ -31,46 +43,62 @@ struct AffArgs {
     const float* qk; const float* qe;
     int HW, top_k, cap, limit;
     int splits, tiles_per_split;
-    float sqrt_ck;
-    float* part_v; int* part_i;
+    int tile_stride;                 // visit tiles 0, R, 2R, ...
+    int sub_tiles;                   // ceil(total_tiles / tile_stride)
+    const float* tau_init;           // [HW] lower bound of the k-th value (select pass) or NULL
+    float sqrt_ck; int sqrt_is_pow2;
+    u64* part_key; int* part_cnt;    // select pass output: [splits][HW][AFF_OUTCAP], [splits][HW]
+    float* bound_part;               // bound pass output: [splits][HW][AFF_BOUND_SLOTS]
 };
 
-__device__ __forceinline__ void rerank(float* cv, int* ci, int c, int top_k, float* tau_q, int* cnt_q, int lane) {
-    float mv[AFF_MAXU]; int mi[AFF_MAXU]; int rk[AFF_MAXU];
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ u64 pack_key(float v, int idx) { return ((u64)f2ord(v) << 32) | (u64)(0xffffffffu - (unsigned)idx); }
+__device__ __forceinline__ float key_val(u64 k) { return ord2f((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_idx(u64 k) { return (int)(0xffffffffu - (unsigned)k); }
+
+// exact re-rank of one query's buffer by counting: larger key first (value, then lower index); keeps top_k sorted
+__device__ __forceinline__ void rerank(u64* ck, int c, int top_k, float* tau_q, int* cnt_q, int lane) {
+    u64 mk[AFF_MAXU]; int rk[AFF_MAXU];
+    const int U = (c + 63) >> 6;
 #pragma unroll
     for (int u = 0; u < AFF_MAXU; ++u) {
         const int e = lane + 64 * u;
-        mv[u] = e < c ? cv[e] : 0.f;
-        mi[u] = e < c ? ci[e] : 0;
+        mk[u] = e < c ? ck[e] : 0ull;
         rk[u] = 0;
     }
-    for (int f = 0; f < c; ++f) {
-        const float vf = cv[f]; const int jf = ci[f];
+    for (int f = 0; f < c; f += 2) {                          // two broadcast keys per 16-B LDS read
+        const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(ck + f);
+        const u64 k1 = (f + 1 < c) ? kf.y : 0ull;
 #pragma unroll
         for (int u = 0; u < AFF_MAXU; ++u)
-            rk[u] += (vf > mv[u]) || (vf == mv[u] && jf < mi[u]);
+            if (u < U) rk[u] += (int)(kf.x > mk[u]) + (int)(k1 > mk[u]);
     }
 #pragma unroll
     for (int u = 0; u < AFF_MAXU; ++u) {
         const int e = lane + 64 * u;
         if (e < c && rk[u] < top_k) {
-            cv[rk[u]] = mv[u]; ci[rk[u]] = mi[u];
-            if (rk[u] == top_k - 1) *tau_q = mv[u];
+            ck[rk[u]] = mk[u];
+            if (rk[u] == top_k - 1) *tau_q = key_val(mk[u]);
         }
     }
     if (lane == 0) *cnt_q = c < top_k ? c : top_k;
 }
 
-template <int CK>
-__global__ __launch_bounds__(256) void affinity_topk_kernel(AffArgs p) {
+template <int CK, bool BOUND>
+__global__ __launch_bounds__(256) void affinity_kernel(AffArgs p) {
     static_assert(CK == 64, "kernel is specialised for C_k = 64");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bq = smem;                               // [64][132]
     float* bsq = Bq + AFF_BQ * AFF_LDB;             // [64]
     float* tau = bsq + AFF_BQ;                      // [64]
     int* cnt = reinterpret_cast<int*>(tau + AFF_BQ);  // [64]
-    float* cand_v = reinterpret_cast<float*>(cnt + AFF_BQ);   // [64][cap]
-    int* cand_i = reinterpret_cast<int*>(cand_v + AFF_BQ * p.cap);
+    u64* cand = reinterpret_cast<u64*>(cnt + AFF_BQ);  // [64][cap]   (select pass only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,18 +130,19 @@ __global__ __launch_bounds__(256) void affinity_topk_kernel(AffArgs p) {
         bs += __shfl_xor(bs, 2, 64);
         if (part == 0) {
             bsq[q] = p.qe ? bs : 0.f;     // no b_sq term without selection (memory_util.py:28-31)
-            tau[q] = -INFINITY;
+            // tau0 is reached by >= k elements; elements equal to it must still pass the strict test below
+            tau[q] = (!BOUND && p.tau_init && qg < p.HW) ? nextafterf(p.tau_init[qg], -INFINITY) : -INFINITY;
             cnt[q] = 0;
         }
     }
     __syncthreads();
 
-    const int t_begin = split * p.tiles_per_split;
-    const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+    const int t_begin = split * p.tiles_per_split;                       // in units of visited (sub-sampled) tiles
+    const int t_end = min(p.sub_tiles, t_begin + p.tiles_per_split);
 
-    // tile -> (segment, row0); returns false for an inactive slot
     auto tile_info = [&](int tile, const float*& key, const float*& shr, int& segn, int& base, int& row0) -> bool {
         if (tile >= t_end) { key = nullptr; shr = nullptr; segn = 0; base = 0; row0 = 0; return false; }
+        tile *= p.tile_stride;
         int s = 0;
 #pragma unroll
         for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
@@ -136,6 +165,13 @@ __global__ __launch_bounds__(256) void affinity_topk_kernel(AffArgs p) {
         msn = (ok && n_shr) ? n_shr[r] : 1.f;
     };
 
+    // bound pass state: the AFF_BOUND_M largest values this lane has seen, per query sub-tile
+    float top[2][AFF_BOUND_M];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int j = 0; j < AFF_BOUND_M; ++j) top[sub][j] = -INFINITY;
+
     issue_loads(t_begin + wave);
     for (int tb = t_begin; tb < t_end; tb += 4) {
         f32x4 a[8];
@@ -147,99 +183,152 @@ __global__ __launch_bounds__(256) void affinity_topk_kernel(AffArgs p) {
         issue_loads(tb + 4 + wave);               // next tile's rows in flight under the MFMAs
 
         if (active) {
+            // two independent accumulator chains (the two 32-query sub-tiles) keep the matrix pipe busy
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            const float* bq0 = Bq + l31 * AFF_LDB + lh * 4;
+            const float* bq1 = bq0 + 32 * AFF_LDB;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 blo0 = *reinterpret_cast<const f32x4*>(bq0 + t * 8);
+                const f32x4 bhi0 = *reinterpret_cast<const f32x4*>(bq0 + CK + t * 8);
+                const f32x4 blo1 = *reinterpret_cast<const f32x4*>(bq1 + t * 8);
+                const f32x4 bhi1 = *reinterpret_cast<const f32x4*>(bq1 + CK + t * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = a[t][j];
+                    const float xx = x * x;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo0[j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo1[j], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi0[j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi1[j], acc1, 0, 0, 0);
+                }
+            }
+            // shrinkage of the 16 rows this lane owns; ((x*ms)/sqrt(Ck)) == x*(ms/sqrt(Ck)) exactly when sqrt(Ck) = 2^j
+            float msr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = __shfl(ms_mine, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+                msr[r] = p.sqrt_is_pow2 ? m / p.sqrt_ck : m;
+            }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const float* bq = Bq + (sub * 32 + l31) * AFF_LDB + lh * 4;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const f32x4 blo = *reinterpret_cast<const f32x4*>(bq + t * 8);
-                    const f32x4 bhi = *reinterpret_cast<const f32x4*>(bq + CK + t * 8);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float x = a[t][j];
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x * x, blo[j], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi[j], acc, 0, 0, 0);
-                    }
-                }
                 const int q = sub * 32 + l31;
                 const float my_tau = tau[q], bs = bsq[q];
                 const bool q_ok = (q0 + q) < p.HW;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float msr = __shfl(ms_mine, rl, 64);
-                    const float v = ((acc[r] - bs) * msr) / p.sqrt_ck;
+                    const float x = ((sub ? acc1[r] : acc0[r]) - bs) * msr[r];
+                    float v = p.sqrt_is_pow2 ? x : x / p.sqrt_ck;
                     const int rr = row0 + rl;
-                    if (q_ok && rr < segn && v > my_tau) {
+                    if (BOUND) {
+                        v = (rr < segn) ? v : -INFINITY;
+#pragma unroll
+                        for (int j = 0; j < AFF_BOUND_M; ++j) {       // branch-free insertion into the sorted survivors
+                            const float hi = fmaxf(top[sub][j], v);
+                            v = fminf(top[sub][j], v);
+                            top[sub][j] = hi;
+                        }
+                    } else if (q_ok && rr < segn && v > my_tau) {
                         const int slot = atomicAdd(&cnt[q], 1);
-                        if (slot < p.cap) { cand_v[q * p.cap + slot] = v; cand_i[q * p.cap + slot] = base + rr; }
+                        if (slot < p.cap) cand[(size_t)q * p.cap + slot] = pack_key(v, base + rr);
                     }
                 }
             }
         }
-        __syncthreads();
-        for (int q = wave; q < AFF_BQ; q += 4) {
-            const int c = cnt[q];
-            if (c > p.limit) rerank(cand_v + q * p.cap, cand_i + q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane);
+        if (!BOUND) {
+            __syncthreads();
+            for (int q = wave; q < AFF_BQ; q += 4) {
+                const int c = cnt[q];
+                if (c > p.limit) rerank(cand + (size_t)q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
-    // ---- final sort of every query's list and hand-off to the merge kernel ----
+    if (BOUND) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qg = q0 + sub * 32 + l31;
+            if (qg < p.HW) {
+                float* o = p.bound_part + ((size_t)split * p.HW + qg) * AFF_BOUND_SLOTS + (wave * 2 + lh) * AFF_BOUND_M;
+#pragma unroll
+                for (int j = 0; j < AFF_BOUND_M; ++j) o[j] = top[sub][j];
+            }
+        }
+        return;
+    }
+    // ---- hand the surviving candidates (unsorted unless re-ranked) to the merge kernel ----
     for (int q = wave; q < AFF_BQ; q += 4) {
         const int qg = q0 + q;
         if (qg >= p.HW) continue;
-        const int c = cnt[q];
-        if (c > 0) rerank(cand_v + q * p.cap, cand_i + q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane);
-        const int kept = c < p.top_k ? c : p.top_k;
-        const size_t o = ((size_t)split * p.HW + qg) * p.top_k;
-        for (int s = lane; s < p.top_k; s += 64) {
-            p.part_v[o + s] = s < kept ? cand_v[q * p.cap + s] : -INFINITY;
-            p.part_i[o + s] = s < kept ? cand_i[q * p.cap + s] : -1;
-        }
+        int c = cnt[q];
+        if (c > AFF_OUTCAP) { rerank(cand + (size_t)q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane); c = min(c, p.top_k); }
+        const size_t o = (size_t)split * p.HW + qg;
+        if (lane == 0) p.part_cnt[o] = c;
+        for (int s = lane; s < c; s += 64) p.part_key[o * AFF_OUTCAP + s] = cand[(size_t)q * p.cap + s];
     }
 }
 
-// one wave per query: merge `splits` sorted lists, emit sorted top-k + softmax weights
-__global__ void affinity_merge_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i, int splits, int HW, int top_k,
-                                      float* __restrict__ out_w, int* __restrict__ out_idx, float* __restrict__ out_sim) {
+// bound pass reduction: tau0[q] = k-th largest of the survivors of all splits (one wave per query)
+__global__ void affinity_bound_kernel(const float* __restrict__ bound_part, int splits, int HW, int top_k, float* __restrict__ tau0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int C = splits * top_k;
-    float* lv = sm + (size_t)wv * (2 * C + 2 * top_k);   // candidate values, then filtered values
-    int* li = reinterpret_cast<int*>(lv + C);
+    const int T = splits * AFF_BOUND_SLOTS;
+    float* v = sm + (size_t)wv * T;
     const int q = blockIdx.x * wpb + wv;
     if (q >= HW) return;
-    float thr = -INFINITY;
-    for (int e = lane; e < C; e += 64) {
-        const int s = e / top_k, r = e - s * top_k;
-        const size_t o = ((size_t)s * HW + q) * top_k + r;
-        lv[e] = part_v[o]; li[e] = part_i[o];
+    for (int e = lane; e < T; e += 64) {
+        const int s = e / AFF_BOUND_SLOTS, r = e - s * AFF_BOUND_SLOTS;
+        v[e] = bound_part[((size_t)s * HW + q) * AFF_BOUND_SLOTS + r];
     }
-    for (int s = lane; s < splits; s += 64) thr = fmaxf(thr, part_v[((size_t)s * HW + q) * top_k + top_k - 1]);
-    thr = wave_max(thr);
-    // in-place stable filter: keep valid candidates >= thr (the global k-th value is >= every split's k-th)
-    int nk = 0;
-    for (int b0 = 0; b0 < C; b0 += 64) {
-        const int e = b0 + lane;
-        const float v = e < C ? lv[e] : 0.f; const int i = e < C ? li[e] : -1;
-        const bool keep = e < C && i >= 0 && v >= thr;
-        const unsigned long long m = __ballot(keep);
-        const int pos = nk + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) { lv[pos] = v; li[pos] = i; }        // pos <= e: never overwrites an unread entry of a later chunk
-        nk += __popcll(m);
-    }
-    // rank by counting; the sorted top-k goes to a private LDS strip first
-    float* sv = reinterpret_cast<float*>(li + C);
-    int* si = reinterpret_cast<int*>(sv + top_k);
-    for (int e = lane; e < nk; e += 64) {
-        const float ve = lv[e]; const int ie = li[e];
+    float res = -INFINITY;      // stays -inf when fewer than k survivors exist
+    for (int e = lane; e < T; e += 64) {
+        const float ve = v[e];
         int rk = 0;
-        for (int f = 0; f < nk; ++f) { const float vf = lv[f]; const int jf = li[f]; rk += (vf > ve) || (vf == ve && jf < ie); }
-        if (rk < top_k) { sv[rk] = ve; si[rk] = ie; }
+        for (int f = 0; f < T; f += 4) {                      // T is a multiple of 16
+            const f32x4 vf = *reinterpret_cast<const f32x4*>(v + f);
+            rk += (int)((vf.x > ve) || (vf.x == ve && f < e)) + (int)((vf.y > ve) || (vf.y == ve && f + 1 < e)) +
+                  (int)((vf.z > ve) || (vf.z == ve && f + 2 < e)) + (int)((vf.w > ve) || (vf.w == ve && f + 3 < e));
+        }
+        if (rk == top_k - 1) res = ve;
+    }
+    res = wave_max(res);
+    if (lane == 0) tau0[q] = res;
+}
+
+// one wave per query: rank the candidates of all splits, emit sorted top-k + softmax weights
+__global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const int* __restrict__ part_cnt, int splits, int HW, int top_k,
+                                      float* __restrict__ out_w, int* __restrict__ out_idx, float* __restrict__ out_sim) {
+    extern __shared__ __attribute__((aligned(16))) u64 smk[];
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x;
+    u64* keys = smk;                                         // [splits * AFF_OUTCAP] (+1 pad)
+    float* sv = reinterpret_cast<float*>(keys + (size_t)splits * AFF_OUTCAP + 2);
+    int* si = reinterpret_cast<int*>(sv + top_k);
+    // counts -> exclusive prefix (splits <= 64: one lane per split)
+    const int my_c = lane < splits ? part_cnt[(size_t)lane * HW + q] : 0;
+    int incl = my_c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const int total = __shfl(incl, 63, 64);
+    const int excl = incl - my_c;
+    for (int s = 0; s < splits; ++s) {
+        const int c = __shfl(my_c, s, 64), off = __shfl(excl, s, 64);
+        if (lane < c) keys[off + lane] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + lane];
+    }
+    if (lane == 0) keys[total] = 0ull;                       // pad for the 2-wide reads below
+    // rank by counting (keys are unique: the index is part of the key)
+    for (int e = lane; e < total; e += 64) {
+        const u64 ke = keys[e];
+        int rk = 0;
+        for (int f = 0; f < total; f += 2) {
+            const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(keys + f);
+            rk += (int)(kf.x > ke) + (int)((f + 1 < total) && (kf.y > ke));
+        }
+        if (rk < top_k) { sv[rk] = key_val(ke); si[rk] = key_idx(ke); }
     }
     // softmax without max shift (memory_util.py:48-49); DS ops of one wave execute in order
     float s = 0.f;
@@ -254,30 +343,54 @@ __global__ void affinity_merge_kernel(const float* __restrict__ part_v, const in
 }
 
 namespace {
-struct AffPlan { int splits, tiles_per_split, total_tiles, limit, cap; size_t lds; };
+struct AffPlan { int splits, tiles_per_split, sub_tiles, limit, cap; size_t lds; };
 
-AffPlan aff_plan(int total_tiles, int HW, int top_k) {
+AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound) {
     AffPlan pl;
-    pl.total_tiles = total_tiles;
+    pl.sub_tiles = sub_tiles;
     const int qtiles = cdiv(HW, AFF_BQ);
-    int s = cdiv(512, qtiles);
-    int maxs = total_tiles / 16; if (maxs < 1) maxs = 1;
+    int s;
+    if (bound) {
+        s = 512 / qtiles;                        // small LDS: two workgroups per CU
+        if (s > 16) s = 16;                      // keeps the survivor list of the bound reduction short
+    } else {
+        // one workgroup per CU (LDS bound): aim for <= 2 full rounds of the 256 CUs, >= 16 tiles (4 steps) per split
+        s = 512 / qtiles;
+        if (s < 1) s = 1;
+        if (sub_tiles / s < 16) s = 256 / qtiles;
+    }
+    if (s < 1) s = 1;
+    int maxs = sub_tiles / 8; if (maxs < 1) maxs = 1;
     if (s > maxs) s = maxs;
     if (s > 64) s = 64;
-    if (s < 1) s = 1;
-    pl.tiles_per_split = cdiv(total_tiles, s);
-    pl.splits = cdiv(total_tiles, pl.tiles_per_split);
-    pl.limit = top_k < 32 ? 32 : (top_k + 7) / 8 * 8;
+    pl.tiles_per_split = cdiv(sub_tiles, s);
+    pl.splits = cdiv(sub_tiles, pl.tiles_per_split);
+    pl.limit = top_k <= 96 ? 96 : (top_k + 7) / 8 * 8;      // re-rank when a buffer holds more than `limit` entries
     pl.cap = pl.limit + AFF_STEP_ROWS;
-    pl.lds = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 2 * (size_t)AFF_BQ * pl.cap) * sizeof(float);
+    pl.lds = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ) * sizeof(float) + (bound ? 0 : (size_t)AFF_BQ * pl.cap * sizeof(u64));
     return pl;
+}
+
+inline int bound_stride(int total_tiles) {
+    // the bound pass samples every 4th 32-row tile (25 % extra MFMA work) once the memory is large enough
+    return total_tiles >= 256 ? 4 : 1;
+}
+
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, total; };
+WsLayout ws_layout(int HW) {
+    WsLayout w;
+    w.key_off = 0;
+    w.cnt_off = align_up((size_t)64 * HW * AFF_OUTCAP * sizeof(u64), 256);
+    w.bound_off = w.cnt_off + align_up((size_t)64 * HW * sizeof(int), 256);
+    w.tau_off = w.bound_off + align_up((size_t)16 * HW * AFF_BOUND_SLOTS * sizeof(float), 256);
+    w.total = w.tau_off + align_up((size_t)HW * sizeof(float), 256);
+    return w;
 }
 }  // namespace
 
 extern "C" size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int top_k) {
     if (n_total <= 0 || HW <= 0 || top_k <= 0) return 0;
-    AffPlan pl = aff_plan(cdiv(n_total, AFF_ROWS) + XMEM_MAX_SEGMENTS, HW, top_k);
-    return (size_t)pl.splits * HW * top_k * 8 + 256;
+    return ws_layout(HW).total;
 }
 
 extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const float* qk, const float* qe, int Ck, int HW,
@@ -285,7 +398,7 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
                                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!segs || n_seg <= 0 || n_seg > XMEM_MAX_SEGMENTS || !qk || !out_w || !out_idx || HW <= 0) return XMEM_ERR_BAD_ARG;
     if (Ck != 64) return XMEM_ERR_UNSUPPORTED;
-    if (top_k < 1 || top_k > 112) return XMEM_ERR_UNSUPPORTED;
+    if (top_k < 1 || top_k > AFF_OUTCAP) return XMEM_ERR_UNSUPPORTED;
     AffArgs a;
     int tiles = 0, base = 0, ns = 0;
     for (int i = 0; i < n_seg; ++i) {
@@ -298,26 +411,42 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     }
     if (base < top_k) return XMEM_ERR_TOPK;
     for (int i = ns; i < XMEM_MAX_SEGMENTS; ++i) { a.seg[i].key = nullptr; a.seg[i].shr = nullptr; a.seg[i].n = 0; a.seg[i].base = base; a.seg[i].tile0 = tiles; a.seg[i].pad = 0; }
-    AffPlan pl = aff_plan(tiles, HW, top_k);
-    const size_t need = (size_t)pl.splits * HW * top_k * 8;
-    if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
-    a.n_seg = ns; a.total_tiles = tiles; a.qk = qk; a.qe = qe; a.HW = HW; a.top_k = top_k; a.cap = pl.cap; a.limit = pl.limit;
-    a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sqrt_ck = sqrtf((float)Ck);
-    a.part_v = reinterpret_cast<float*>(workspace);
-    a.part_i = reinterpret_cast<int*>(a.part_v + (size_t)pl.splits * HW * top_k);
+    const WsLayout wl = ws_layout(HW);
+    if (!workspace || workspace_bytes < wl.total) return XMEM_ERR_WORKSPACE;
+    char* ws = reinterpret_cast<char*>(workspace);
+    a.n_seg = ns; a.total_tiles = tiles; a.qk = qk; a.qe = qe; a.HW = HW; a.top_k = top_k;
+    a.sqrt_ck = sqrtf((float)Ck);
+    { int e = 0; const float m = frexpf(a.sqrt_ck, &e); a.sqrt_is_pow2 = (m == 0.5f); }
+    a.part_key = reinterpret_cast<u64*>(ws + wl.key_off);
+    a.part_cnt = reinterpret_cast<int*>(ws + wl.cnt_off);
+    a.bound_part = reinterpret_cast<float*>(ws + wl.bound_off);
+    float* tau0 = reinterpret_cast<float*>(ws + wl.tau_off);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    auto kern = affinity_topk_kernel<64>;
+    int rc;
+    const int R = bound_stride(tiles);
+    a.tau_init = nullptr;
+    if (R > 1) {
+        AffPlan pa = aff_plan(cdiv(tiles, R), HW, top_k, true);
+        a.cap = 0; a.limit = 0; a.splits = pa.splits; a.tiles_per_split = pa.tiles_per_split; a.sub_tiles = pa.sub_tiles;
+        a.tile_stride = R;
+        hipLaunchKernelGGL((affinity_kernel<64, true>), dim3(cdiv(HW, AFF_BQ), pa.splits), dim3(256), pa.lds, s, a);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        const int T = pa.splits * AFF_BOUND_SLOTS;
+        hipLaunchKernelGGL(affinity_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), (size_t)4 * T * sizeof(float), s,
+                           a.bound_part, pa.splits, HW, top_k, tau0);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        a.tau_init = tau0;
+    }
+    AffPlan pl = aff_plan(tiles, HW, top_k, false);
+    a.cap = pl.cap; a.limit = pl.limit; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
+    a.tile_stride = 1;
+    auto kern = affinity_kernel<64, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
         return XMEM_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
-    int rc = xmem_check_launch();
-    if (rc != XMEM_OK) return rc;
-    const int C = pl.splits * top_k;
-    int wpb = 4;
-    while (wpb > 1 && (size_t)wpb * (2 * C + 2 * top_k) * 4 > 60 * 1024) wpb >>= 1;
-    const size_t mlds = (size_t)wpb * (2 * C + 2 * top_k) * 4;
-    if (mlds > 64 * 1024) return XMEM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(affinity_merge_kernel, dim3(cdiv(HW, wpb)), dim3(64 * wpb), mlds, s, a.part_v, a.part_i, pl.splits, HW, top_k,
+    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    const size_t mlds = ((size_t)pl.splits * AFF_OUTCAP + 2) * sizeof(u64) + (size_t)2 * top_k * sizeof(float);
+    hipLaunchKernelGGL(affinity_merge_kernel, dim3(HW), dim3(64), mlds, s, a.part_key, a.part_cnt, pl.splits, HW, top_k,
                        out_w, out_idx, out_sim);
     return xmem_check_launch();
 }

@@ -71,7 +71,7 @@ class XMem:
             if missing or unexpected:
                 raise RuntimeError(f'Error(s) in loading state_dict for XMem: missing {missing[:5]}..., unexpected {unexpected[:5]}...')
             for k, shape in spec.items():
-                if k in sd and tuple(sd[k].shape) != tuple(shape):
+                if k in sd and tuple(sd[k].shape) != tuple(shape) and not (len(shape) == 0 and sd[k].numel() == 1):
                     raise RuntimeError(f'size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(shape)}')
         self._sd = {k: v.detach().to('cpu') for k, v in sd.items()}
         if self.device.type == 'cuda':
@@ -116,7 +116,7 @@ class XMem:
             scale = torch.ones(cout)
             shift = sd[name + '.bias'].float() if (name + '.bias') in sd else torch.zeros(cout)
         dev = self.device
-        return ConvWeights(wk.contiguous().to(dev), scale.contiguous().to(dev), shift.contiguous().to(dev), stride, pad)
+        return ConvWeights(wk.contiguous().to(dev), scale.contiguous().to(dev), shift.contiguous().to(dev), stride, pad, cin_true=cin)
 
     def _upload(self):
         sd, W = self._sd, {}
@@ -146,7 +146,7 @@ class XMem:
         if W['value_encoder.conv1'].cin != 8:       # 5 (or 4) input channels live in an 8-channel packed tensor
             cw = W['value_encoder.conv1']
             wk = torch.nn.functional.pad(cw.w, (0, 8 - cw.cin))
-            W['value_encoder.conv1'] = ConvWeights(wk.contiguous(), cw.scale, cw.shift, 2, 3)
+            W['value_encoder.conv1'] = ConvWeights(wk.contiguous(), cw.scale, cw.shift, 2, 3, cin_true=cw.cin_true)
         basic_stage('value_encoder.layer1', 2, 1)
         basic_stage('value_encoder.layer2', 2, 2)
         basic_stage('value_encoder.layer3', 2, 2)
@@ -187,7 +187,7 @@ class XMem:
         parts = [self._conv_w('key_proj.' + n, None, 1, 1) for n in ('key_proj', 'd_proj', 'e_proj')]
         W['key_proj'] = ConvWeights(torch.cat([p.w for p in parts], 0).contiguous(),
                                     torch.cat([p.scale for p in parts], 0).contiguous(),
-                                    torch.cat([p.shift for p in parts], 0).contiguous(), 1, 1)
+                                    torch.cat([p.shift for p in parts], 0).contiguous(), 1, 1, cin_true=parts[0].cin_true)
         self._w = W
 
     def _need_weights(self):

@@ -13,6 +13,38 @@ from ._lib import ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_p
 
 _workspaces = {}
 
+# Optional live kernel timing for bench.py: PROFILE = {} enables HIP events (torch events record on the current
+# stream, which is the stream every kernel here is launched on) around the conv and affinity launches.
+PROFILE = None
+_events = []
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(kind, start, flop):
+    if start is None:
+        return
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _events.append((kind, start, e, flop))
+
+
+def collect_profile():
+    """Synchronise and fold the recorded events: {kind: {ms, flop, launches}}."""
+    torch.cuda.synchronize()
+    out = {}
+    for kind, a, b, flop in _events:
+        d = out.setdefault(kind, dict(ms=0.0, flop=0.0, launches=0))
+        d['ms'] += a.elapsed_time(b); d['flop'] += flop; d['launches'] += 1
+    _events.clear()
+    return out
+
 
 def workspace(nbytes, device, tag='default'):
     """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so reuse is safe."""
@@ -34,12 +66,13 @@ def _req(t, name):
 
 class ConvWeights:
     """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
-    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad')
+    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true')
 
-    def __init__(self, w, scale, shift, stride, pad):
+    def __init__(self, w, scale, shift, stride, pad, cin_true=None):
         self.w, self.scale, self.shift = w, scale, shift
         self.cout, self.kh, self.kw, self.cin = w.shape
         self.stride, self.pad = stride, pad
+        self.cin_true = cin_true if cin_true is not None else self.cin     # un-padded Cin (algorithmic FLOPs)
 
 
 def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None):
@@ -68,7 +101,9 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(need, x.device, 'conv') if need else None
+    ev = _prof_begin()
     check(lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()))
+    _prof_end('conv', ev, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true)
     return out
 
 
@@ -237,8 +272,10 @@ def affinity_topk(segments, qk, qe, top_k, want_sim=False):
     sim = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device) if want_sim else None
     need = lib.xmem_affinity_topk_workspace_bytes(n_total, HW, top_k)
     ws = workspace(need, qk.device, 'affinity')
+    ev = _prof_begin()
     check(lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
                                  ptr(ws), need, stream_ptr()))
+    _prof_end('affinity', ev, 4.0 * ck * n_total * HW)
     return w, idx, sim
 
 

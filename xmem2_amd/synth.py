@@ -99,7 +99,8 @@ def synthetic_state_dict(seed=0, key_dim=64, value_dim=512, hidden_dim=64, as_to
         out[name] = arr
     if as_torch:
         import torch
-        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
+        return {k: (torch.from_numpy(np.ascontiguousarray(v)) if v.ndim else torch.tensor(int(v), dtype=torch.int64))
+                for k, v in out.items()}
     return out
 
 
