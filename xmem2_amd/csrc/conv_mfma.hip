@@ -202,6 +202,40 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs p) {
     }
 }
 
+// Cout == 1 (the decoder's mask head, model/modules.py:242): a GEMV per pixel - one wave per output pixel,
+// lanes over input channels (float4), wave reduction.  HBM/L2-bound instead of wasting a 64-wide MFMA tile.
+__global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int b = m / p.HoWo, rem = m - b * p.HoWo;
+    const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+    float acc = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh) {
+        const int ih = oh * p.stride - p.pad + kh;
+        if ((unsigned)ih >= (unsigned)p.H) continue;
+        for (int kw = 0; kw < p.KW; ++kw) {
+            const int iw = ow * p.stride - p.pad + kw;
+            if ((unsigned)iw >= (unsigned)p.W) continue;
+            const float* x = p.in + ((size_t)(b * p.H + ih) * p.W + iw) * p.ldin;
+            const float* w = p.w + (size_t)(kh * p.KW + kw) * p.Cin;
+            for (int c = lane * 4; c < p.Cin; c += 256) {
+                f32x4 xv = *reinterpret_cast<const f32x4*>(x + c);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+                if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+                acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc * p.scale[0] + p.shift[0];
+        if (p.res) v += p.res[(size_t)m * p.ldres];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        p.out[(size_t)m * p.ldout] = v;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
@@ -230,6 +264,7 @@ Plan make_plan(const xmem_conv_desc* d) {
     Plan pl;
     pl.generic = (d->Cin % BK) != 0;
     pl.nk = cdiv(K, BK);
+    if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
     // 256 CUs; two resident workgroups per CU is the sweet spot for the 128-wide tiles
     if (d->Cout > 64 && tiles(128, 128) >= 384) { pl.bm = 128; pl.bn = 128; }
@@ -286,12 +321,16 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     a.K = d->KH * d->KW * d->Cin; a.M = d->B * Ho * Wo; a.HoWo = Ho * Wo;
     a.relu_in = d->relu_in; a.relu_out = d->relu_out;
     a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
-    a.tiles_m = cdiv(a.M, pl.bm); a.tiles_n = cdiv(a.Cout, pl.bn);
+    a.tiles_m = pl.bm ? cdiv(a.M, pl.bm) : 0; a.tiles_n = pl.bn ? cdiv(a.Cout, pl.bn) : 0;
     if (pl.splitk > 1) {
         const size_t need = (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
         if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (pl.bm == 0) {
+        hipLaunchKernelGGL(conv_cout1_kernel, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
+        return xmem_check_launch();
+    }
     if (pl.bm == 128 && pl.bn == 128)
         rc = pl.generic ? launch_cfg<128, 128, 2, 2, true>(a, s) : launch_cfg<128, 128, 2, 2, false>(a, s);
     else if (pl.bm == 128 && pl.bn == 64)

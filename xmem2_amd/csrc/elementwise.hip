@@ -162,16 +162,19 @@ extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* 
 //   3. compress:       per pixel max / mean over c of g*cscale             -> comp [B][P][2]
 //   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg
 // ---------------------------------------------------------------------------------------------
-__global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __restrict__ pooled, int P, int C) {
-    // block = 256 threads = 64 channels x 4 pixel stripes; grid = (C/64, B)
+#define CBAM_PSPLIT 16
+__global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __restrict__ partial, int P, int C) {
+    // block = 256 threads = 64 channels x 4 pixel stripes; grid = (C/64, B, CBAM_PSPLIT); partial [B][PSPLIT][2][C]
     __shared__ float ssum[4][64];
     __shared__ float smax[4][64];
     const int cl = threadIdx.x & 63, stripe = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y, ps = blockIdx.z;
+    const int per = (P + CBAM_PSPLIT - 1) / CBAM_PSPLIT;
+    const int p0 = ps * per, p1 = min(P, p0 + per);
     float s = 0.f, m = -INFINITY;
     if (c < C) {
         const float* gb = g + (size_t)b * P * C + c;
-        for (int pidx = stripe; pidx < P; pidx += 4) {
+        for (int pidx = p0 + stripe; pidx < p1; pidx += 4) {
             const float v = gb[(size_t)pidx * C];
             s += v; m = fmaxf(m, v);
         }
@@ -181,18 +184,27 @@ __global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __r
     if (stripe == 0 && c < C) {
         const float ts = (ssum[0][cl] + ssum[1][cl]) + (ssum[2][cl] + ssum[3][cl]);
         const float tm = fmaxf(fmaxf(smax[0][cl], smax[1][cl]), fmaxf(smax[2][cl], smax[3][cl]));
-        pooled[((size_t)b * 2 + 0) * C + c] = ts / (float)P;
-        pooled[((size_t)b * 2 + 1) * C + c] = tm;
+        partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 0) * C + c] = ts;
+        partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 1) * C + c] = tm;
     }
 }
 
-__global__ void cbam_channel_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ b1,
+__global__ void cbam_channel_mlp_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                        float* __restrict__ cscale, int C, int Cr) {
-    // one block per b; hidden [2][Cr] in LDS
+                                        float* __restrict__ cscale, int P, int C, int Cr) {
+    // one block per b; pooled [2][C] then hidden [2][Cr] in LDS
     extern __shared__ float hid[];
+    float* pb = hid + 2 * Cr;
     const int b = blockIdx.x;
-    const float* pb = pooled + (size_t)b * 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f, m = -INFINITY;
+        for (int ps = 0; ps < CBAM_PSPLIT; ++ps) {
+            s += partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 0) * C + c];
+            m = fmaxf(m, partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 1) * C + c]);
+        }
+        pb[c] = s / (float)P; pb[C + c] = m;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int o = wave; o < 2 * Cr; o += nw) {
         const int which = o / Cr, j = o - which * Cr;
@@ -274,7 +286,7 @@ __global__ void cbam_apply_kernel(const float* __restrict__ g, const float* __re
 
 extern "C" size_t xmem_cbam_workspace_bytes(int B, int P, int C) {
     if (B <= 0 || P <= 0 || C <= 0) return 0;
-    return align_up((size_t)B * 2 * C * 4, 256) + align_up((size_t)B * C * 4, 256) +
+    return align_up((size_t)B * CBAM_PSPLIT * 2 * C * 4, 256) + align_up((size_t)B * C * 4, 256) +
            align_up((size_t)B * P * 2 * 4, 256) + align_up((size_t)B * P * 4, 256);
 }
 
@@ -286,13 +298,13 @@ extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int 
     const int P = H * W, Cr = C / 16;
     if (!workspace || workspace_bytes < xmem_cbam_workspace_bytes(B, P, C)) return XMEM_ERR_WORKSPACE;
     char* ws = (char*)workspace;
-    float* pooled = (float*)ws; ws += align_up((size_t)B * 2 * C * 4, 256);
+    float* pooled = (float*)ws; ws += align_up((size_t)B * CBAM_PSPLIT * 2 * C * 4, 256);
     float* cscale = (float*)ws; ws += align_up((size_t)B * C * 4, 256);
     float* comp = (float*)ws;   ws += align_up((size_t)B * P * 2 * 4, 256);
     float* sgate = (float*)ws;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(cdiv(C, 64), B), dim3(256), 0, s, g, pooled, P, C);
-    hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(256), 2 * Cr * sizeof(float), s, pooled, w1, b1, w2, b2, cscale, C, Cr);
+    hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(cdiv(C, 64), B, CBAM_PSPLIT), dim3(256), 0, s, g, pooled, P, C);
+    hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(512), (2 * Cr + 2 * C) * sizeof(float), s, pooled, w1, b1, w2, b2, cscale, P, C, Cr);
     hipLaunchKernelGGL(cbam_compress_kernel, dim3(grid_for((size_t)B * P, 4)), dim3(256), 0, s, g, cscale, comp, B * P, P, C);
     hipLaunchKernelGGL(cbam_spatial_gate_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, s, comp, sw, sb, sgate, B, H, W);
     hipLaunchKernelGGL(cbam_apply_kernel, dim3(grid_for((size_t)B * P * (C / 4))), dim3(256), 0, s, g, cscale, sgate, out, B * P, P, C / 4);

@@ -21,7 +21,8 @@ class InferenceCore:
         # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
         if getattr(network, 'device', None) is not None and network.device.type == 'cuda':
             with torch.cuda.device(network.device):
-                self.network.encode_key_nhwc(torch.zeros((1, 64, 64, 4), device=network.device))
+                self.network._need_weights()
+                self.network._encode_key_eager(torch.zeros((1, 64, 64, 4), device=network.device), True, True)
 
     def _read_config(self, config):
         self.mem_every = config['mem_every']
@@ -76,7 +77,7 @@ class InferenceCore:
         """inference_core.py:53-61."""
         image4, _, _ = self._pack(image)
         key, shr, sel, f16, _, _ = self.network.encode_key_nhwc(image4, need_sk=True, need_ek=True)
-        return self._key_views(key, shr, sel, f16.shape[1], f16.shape[2])
+        return tuple(v.clone() for v in self._key_views(key, shr, sel, f16.shape[1], f16.shape[2]))
 
     # ---- the per-frame step ----------------------------------------------------------------------
     def step(self, image, mask=None, valid_labels=None, end=False, manually_curated_masks=False,
@@ -144,7 +145,8 @@ class InferenceCore:
                 self.last_deep_update_ti = self.curr_ti
 
         if return_key_and_stuff:
-            return (prob,) + self._key_views(key, shrinkage, selection, h, w)
+            views = self._key_views(key, shrinkage, selection, h, w)
+            return (prob,) + tuple(v.clone() if v is not None else None for v in views)   # caller-owned copies
         return prob
 
     def put_to_permanent_memory(self, image, mask, ti=None):

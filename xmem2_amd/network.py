@@ -10,6 +10,7 @@ loads unchanged.  Internally nothing is an nn.Module: at load time every convolu
 Public methods take / return NCHW-shaped tensors like the reference (zero-copy permuted views of the
 NHWC buffers); the ``*_nhwc`` methods are the hot path used by ``InferenceCore``.
 """
+import os
 import warnings
 
 import torch
@@ -32,6 +33,9 @@ class XMem:
         self._sd = None
         self._w = {}
         self._cbam = {}
+        # launch-bound stages (61 convolutions + ~40 small kernels per frame) are replayed as HIP graphs
+        self.use_graphs = os.environ.get('XMEM_HIP_GRAPHS', '1') != '0'
+        self._stages = {}
         weights = self.init_hyperparameters(config, model_path, map_location)
         if weights is not None:
             self.load_weights(weights, init_as_zero_if_needed=True)
@@ -200,6 +204,36 @@ class XMem:
                 raise RuntimeError('xmem2_amd.XMem runs on an MI355X (HIP) device only; call .to("cuda") - there is no CPU path')
             self._upload()
 
+    # ---- HIP-graph staging ------------------------------------------------------------------------
+    def _run_stage(self, name, key, inputs, fn, alias=()):
+        """Run `fn(*inputs)` eagerly, or capture it once per (name, shapes, flags) into a HIP graph with static
+        input / output buffers and replay it.  Kernels are launched through ctypes on torch's current stream, which
+        is the capturing stream inside torch.cuda.graph, so they are captured like any other launch."""
+        if not self.use_graphs or ops.PROFILE is not None:
+            return fn(*inputs)
+        full_key = (name, key) + tuple(tuple(t.shape) if t is not None else None for t in inputs)
+        st = self._stages.get(full_key)
+        if st is None:
+            # inputs listed in `alias` are themselves stable buffers (outputs of another stage): use them in place
+            static_in = [(t if i in alias else t.clone()) if t is not None else None for i, t in enumerate(inputs)]
+            fn(*static_in)                                  # warm-up: sizes every workspace before the capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = fn(*static_in)
+            st = (graph, static_in, static_out)
+            self._stages[full_key] = st
+        graph, static_in, static_out = st
+        for dst, src in zip(static_in, inputs):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        graph.replay()
+        return static_out
+
+    def _is_stage_output(self, t):
+        return any(any(o is not None and o.data_ptr() == t.data_ptr() for o in st[2]) for k, st in self._stages.items()
+                   if k[0] == 'key')
+
     # ---- building blocks (NHWC) -----------------------------------------------------------------
     def _bottleneck(self, x, p):
         W = self._w
@@ -234,8 +268,13 @@ class XMem:
 
     # ---- hot path (NHWC) ------------------------------------------------------------------------
     def encode_key_nhwc(self, image4, need_sk=True, need_ek=True):
-        """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC)."""
+        """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC).
+        With graphs on, the returned tensors are the stage's static buffers: valid until the next call."""
         self._need_weights()
+        return self._run_stage('key', (need_sk, need_ek), [image4],
+                               lambda im: self._encode_key_eager(im, need_sk, need_ek))
+
+    def _encode_key_eager(self, image4, need_sk, need_ek):
         W = self._w
         x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
         x = ops.maxpool3x3s2(x)
@@ -252,6 +291,14 @@ class XMem:
     def encode_value_nhwc(self, image4, f16, hidden, masks, is_deep_update=True):
         """image4 [1,Hp,Wp,4], f16 [1,h,w,1024], hidden [K,h,w,Ch], masks [K,Hp,Wp] -> value [K,h,w,Cv], hidden."""
         self._need_weights()
+        value, new_hidden = self._run_stage('value', (bool(is_deep_update),), [image4, f16, hidden, masks],
+                                            lambda a, b, c, d: self._encode_value_eager(a, b, c, d, is_deep_update),
+                                            alias=(1,) if self._is_stage_output(f16) else ())
+        if self.use_graphs and new_hidden is not None and new_hidden is not hidden:
+            new_hidden = new_hidden.clone()                 # the hidden state outlives the stage's static buffer
+        return value, new_hidden
+
+    def _encode_value_eager(self, image4, f16, hidden, masks, is_deep_update):
         W = self._w
         x = ops.pack_value_input(image4, masks)
         g = ops.conv2d(x, W['value_encoder.conv1'], relu_out=True)     # relu and max-pool commute (modules.py:137-138)
@@ -273,13 +320,28 @@ class XMem:
         return value, hidden
 
     def new_decoder_input(self, K, h, w, device):
-        """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place."""
-        return torch.empty((K, h, w, 1024 + self.value_dim + self.hidden_dim), dtype=torch.float32, device=device)
+        """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
+        Once the decoder stage is captured this is its static input buffer (no copy before the replay)."""
+        shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
+        if self.use_graphs and ops.PROFILE is None:
+            for k, st in self._stages.items():
+                if k[0] == 'segment' and tuple(st[1][3].shape) == shape:
+                    return st[1][3]
+        return torch.empty(shape, dtype=torch.float32, device=device)
 
     def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True):
         """Decoder + soft aggregation.  cat16 holds the memory readout at channels [1024,1024+Cv).
         Returns new_hidden|None, prob [K+1,H,W] (unpadded), prob_padded [K+1,Hp,Wp]."""
         self._need_weights()
+        out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out)), [f16, f8, f4, cat16, hidden],
+                              lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out),
+                              alias=(0, 1, 2) if self._is_stage_output(f16) else ())
+        if self.use_graphs and ops.PROFILE is None:
+            new_hidden, prob, prob_padded = out              # hidden / prob outlive the stage's static buffers
+            return (new_hidden.clone() if new_hidden is not None else None), prob.clone(), prob_padded
+        return out
+
+    def _segment_eager(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out):
         W = self._w
         K, h, w, _ = cat16.shape
         hd = self.hidden_dim
