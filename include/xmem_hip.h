@@ -60,6 +60,8 @@ typedef struct {
     const float* res;   int ldres;
     float* out;         int ldout;
     int relu_in, relu_out;
+    int plan_tile;      /* 0 = built-in heuristic; 1..6 = {128x128, 128x64, 64x64} x {BK 32, BK 64} (autotuner override) */
+    int plan_splitk;    /* 0 = heuristic; >0 = number of K splits */
 } xmem_conv_desc;
 
 size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);

@@ -1,0 +1,25 @@
+"""Run the B32 workload (and the test geometries) once with the autotuner on and dump the measured conv plans."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.set_grad_enabled(False)
+from xmem2_amd import ops, XMem, InferenceCore
+from xmem2_amd.synth import synthetic_state_dict, synthetic_frames, synthetic_masks
+import bench
+
+ops._plans = {}            # ignore shipped plans: re-measure everything
+net = XMem(dict(bench.b32_config()), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
+net.use_graphs = False
+for (H, W, K) in [(480, 854, 1), (480, 854, 2), (720, 1280, 1)]:
+    cfg = bench.b32_config(); cfg['mem_every'] = 2
+    fr = torch.from_numpy(synthetic_frames(4, H, W)).cuda(); mk = torch.from_numpy(synthetic_masks(4, K, H, W)).cuda()
+    core = InferenceCore(net, cfg); core.set_all_labels(list(range(1, K + 1)))
+    core.put_to_permanent_memory(fr[0], mk[0])
+    for t in range(1, 4):
+        core.step(fr[t], None, None)
+    torch.cuda.synchronize()
+    print(H, W, K, 'plans so far', len(ops._tuned_now))
+n = ops.dump_tuned_plans(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/conv_plans.json')
+print('dumped', n)
+for k, v in sorted(ops._tuned_now.items()):
+    print(k, v)

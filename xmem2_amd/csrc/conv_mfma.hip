@@ -14,8 +14,9 @@
 // Replaces the nn.Conv2d/BatchNorm2d/ReLU/residual call sites listed in include/xmem_hip.h.
 #include "common.hpp"
 
-#define BK 32
-#define LDK 36
+// BK (k-depth of a staged tile) is a template parameter: 32 or 64.  LDS rows are padded by 4 floats:
+// stride 36 (=9x16 B) or 68 (=17x16 B) floats; both are odd multiples of 16 B, so the 16 lanes of a ds_read_b128
+// lane-group (16 distinct rows) fall on 16 distinct 16-B slots of the 256-B bank row.
 
 struct ConvArgs {
     const float* in; const float* w; const float* scale; const float* shift; const float* res;
@@ -29,12 +30,15 @@ struct ConvArgs {
     int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int TM, int TN, bool GENERIC>
+template <int BM, int BN, int TM, int TN, int BK, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WN = BN / (32 * TN);
     constexpr int WM = BM / (32 * TM);
     static_assert(WM * WN == 4, "four waves per workgroup");
-    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int LDK = BK + 4;
+    constexpr int C4 = BK / 4;                 // float4 columns per staged row
+    constexpr int RPP = 256 / C4;              // rows staged per pass of the 256 threads
+    constexpr int RA = BM / RPP, RB = BN / RPP;
     constexpr int BUF = (BM + BN) * LDK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int lrow = tid >> 3, c4 = tid & 7;
+    const int lrow = tid / C4, c4 = tid % C4;
 
     // XCD-aware tile order: consecutive tile ids (same M-tile, neighbouring N-tiles) stay on one XCD / L2.
     int bid = blockIdx.x;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     int a_ih0[RA], a_iw0[RA], a_pix[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RPP * i;
         if (m < p.M) {
             const int b = m / p.HoWo, rem = m - b * p.HoWo;
             const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         const int kb = k0 + c4 * 4;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int n = n0 + lrow + 32 * i;
+            const int n = n0 + lrow + RPP * i;
             const bool ok = n < p.Cout && kb < p.K;
             rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + kb) : zero;
         }
@@ -117,9 +121,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         float* As = smem + buf * BUF;
         float* Bs = As + BM * LDK;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDK + c4 * 4]) = ra[i];
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * LDK + c4 * 4]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDK + c4 * 4]) = rb[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * i) * LDK + c4 * 4]) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, splitk, kt_per_split, nk; bool generic; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; };
 
 int validate(const xmem_conv_desc* d) {
     if (!d || !d->in || !d->w || !d->scale || !d->shift || !d->out) return XMEM_ERR_BAD_ARG;
@@ -250,6 +254,7 @@ int validate(const xmem_conv_desc* d) {
     if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
     if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
     if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
+    if (d->plan_tile < 0 || d->plan_tile > 6 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
     return XMEM_OK;
 }
 
@@ -258,36 +263,48 @@ inline void out_dims(const xmem_conv_desc* d, int& Ho, int& Wo) {
     Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
 }
 
+// plan_tile: 0 = heuristic, 1..6 = {128x128, 128x64, 64x64} x {BK 32, BK 64}
 Plan make_plan(const xmem_conv_desc* d) {
     int Ho, Wo; out_dims(d, Ho, Wo);
     const int M = d->B * Ho * Wo, K = d->KH * d->KW * d->Cin;
     Plan pl;
-    pl.generic = (d->Cin % BK) != 0;
-    pl.nk = cdiv(K, BK);
-    if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
+    pl.bk = 32;
+    pl.generic = false;
+    if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
-    // 256 CUs; two resident workgroups per CU is the sweet spot for the 128-wide tiles
-    if (d->Cout > 64 && tiles(128, 128) >= 384) { pl.bm = 128; pl.bn = 128; }
-    else if (tiles(128, 64) >= 384) { pl.bm = 128; pl.bn = 64; }
-    else { pl.bm = 64; pl.bn = 64; }
+    if (d->plan_tile > 0) {
+        static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
+        pl.bm = cfg[d->plan_tile - 1][0]; pl.bn = cfg[d->plan_tile - 1][1]; pl.bk = cfg[d->plan_tile - 1][2];
+    } else {
+        // 256 CUs; two resident workgroups per CU is the sweet spot for the 128-wide tiles
+        if (d->Cout > 64 && tiles(128, 128) >= 384) { pl.bm = 128; pl.bn = 128; }
+        else if (tiles(128, 64) >= 384) { pl.bm = 128; pl.bn = 64; }
+        else { pl.bm = 64; pl.bn = 64; }
+    }
+    pl.generic = (d->Cin % pl.bk) != 0;
+    pl.nk = cdiv(K, pl.bk);
     pl.splitk = 1;
-    const long t = tiles(pl.bm, pl.bn);
-    if (t < 384) {
-        int want = (int)cdiv(512, (int)t);
-        int maxs = pl.nk / 8; if (maxs < 1) maxs = 1;
-        pl.splitk = want < maxs ? want : maxs;
-        if (pl.splitk > 16) pl.splitk = 16;
-        if (pl.splitk < 1) pl.splitk = 1;
+    if (d->plan_splitk > 0) {
+        pl.splitk = d->plan_splitk < pl.nk ? d->plan_splitk : pl.nk;
+    } else {
+        const long t = tiles(pl.bm, pl.bn);
+        if (t < 384) {
+            int want = (int)cdiv(512, (int)t);
+            int maxs = pl.nk / (256 / pl.bk); if (maxs < 1) maxs = 1;
+            pl.splitk = want < maxs ? want : maxs;
+            if (pl.splitk > 16) pl.splitk = 16;
+            if (pl.splitk < 1) pl.splitk = 1;
+        }
     }
     pl.kt_per_split = cdiv(pl.nk, pl.splitk);
     pl.splitk = cdiv(pl.nk, pl.kt_per_split);
     return pl;
 }
 
-template <int BM, int BN, int TM, int TN, bool G>
+template <int BM, int BN, int TM, int TN, int BK, bool G>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * LDK * sizeof(float);
-    auto kern = conv_mfma_kernel<BM, BN, TM, TN, G>;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
@@ -295,6 +312,13 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return xmem_check_launch();
+}
+
+template <int BK, bool G>
+int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s) {
+    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s);
+    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s);
+    return launch_cfg<64, 64, 1, 1, BK, G>(a, s);
 }
 
 }  // namespace
@@ -331,12 +355,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         hipLaunchKernelGGL(conv_cout1_kernel, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
         return xmem_check_launch();
     }
-    if (pl.bm == 128 && pl.bn == 128)
-        rc = pl.generic ? launch_cfg<128, 128, 2, 2, true>(a, s) : launch_cfg<128, 128, 2, 2, false>(a, s);
-    else if (pl.bm == 128 && pl.bn == 64)
-        rc = pl.generic ? launch_cfg<128, 64, 2, 1, true>(a, s) : launch_cfg<128, 64, 2, 1, false>(a, s);
-    else
-        rc = pl.generic ? launch_cfg<64, 64, 1, 1, true>(a, s) : launch_cfg<64, 64, 1, 1, false>(a, s);
+    if (pl.bk == 64) rc = pl.generic ? launch_bk<64, true>(pl, a, s) : launch_bk<64, false>(pl, a, s);
+    else rc = pl.generic ? launch_bk<32, true>(pl, a, s) : launch_bk<32, false>(pl, a, s);
     if (rc != XMEM_OK) return rc;
     if (pl.splitk > 1) {
         const size_t total = (size_t)a.M * a.Cout;

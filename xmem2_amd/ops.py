@@ -5,6 +5,8 @@ Everything here takes / returns torch CUDA tensors in the kernels' native layout
 torch is plumbing only: allocation, streams.  No torch compute op is used on the product path.
 """
 import ctypes as C
+import json
+import os
 
 import torch
 
@@ -75,6 +77,74 @@ class ConvWeights:
         self.cin_true = cin_true if cin_true is not None else self.cin     # un-padded Cin (algorithmic FLOPs)
 
 
+# ---- convolution plans ---------------------------------------------------------------------------------------
+# Tile shape / split-K of the implicit-GEMM kernel are chosen per layer shape.  Plans measured on an MI355X are
+# shipped in conv_plans.json (deterministic: the same plan -> the same summation order); shapes not listed there
+# are timed once at first use (XMEM_CONV_AUTOTUNE=0 falls back to the library's built-in heuristic).
+AUTOTUNE = os.environ.get('XMEM_CONV_AUTOTUNE', '1') != '0'
+_PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_plans.json')
+_plans = None
+_tuned_now = {}
+
+
+def _load_plans():
+    global _plans
+    if _plans is None:
+        _plans = {}
+        if os.path.exists(_PLAN_FILE):
+            try:
+                _plans = {k: tuple(v) for k, v in json.load(open(_PLAN_FILE)).items()}
+            except Exception:
+                _plans = {}
+    return _plans
+
+
+def dump_tuned_plans(path):
+    """Write every plan known to this process (shipped + tuned now) - used to refresh conv_plans.json."""
+    allp = dict(_load_plans())
+    allp.update(_tuned_now)
+    with open(path, 'w') as f:
+        json.dump({k: list(v) for k, v in sorted(allp.items())}, f, indent=0)
+    return len(allp)
+
+
+def _tune_conv(lib, d, x_device):
+    """Time the candidate (tile, split-K) plans for this descriptor; returns the fastest."""
+    Ho = (d.H + 2 * d.pad - d.KH) // d.stride + 1
+    Wo = (d.W + 2 * d.pad - d.KW) // d.stride + 1
+    M, K = d.B * Ho * Wo, d.KH * d.KW * d.Cin
+    best, best_t = (0, 0), None
+    tiles = {1: (128, 128, 32), 2: (128, 64, 32), 3: (64, 64, 32), 4: (128, 128, 64), 5: (128, 64, 64), 6: (64, 64, 64)}
+    for tile, (bm, bn, bk) in tiles.items():
+        if bn == 128 and d.Cout <= 64:
+            continue
+        nt = -(-M // bm) * -(-d.Cout // bn)
+        nk = -(-K // bk)
+        for sk in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sk > 1 and (nt * sk > 2048 or nk // sk < 2):
+                continue
+            if sk == 1 and nt < 48 and nk >= 16:
+                continue
+            d.plan_tile, d.plan_splitk = tile, sk
+            need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
+            ws = workspace(need, x_device, 'conv') if need else None
+            st = stream_ptr()
+            for _ in range(2):
+                if lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, st) != 0:
+                    break
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(4):
+                    lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, st)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if best_t is None or t < best_t:
+                    best, best_t = (tile, sk), t
+    return best
+
+
 def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None):
     """x [B,H,W,C] NHWC (or any buffer whose pixel stride is `in_ld`) -> out [B,Ho,Wo,Cout]."""
     lib = load()
@@ -99,6 +169,14 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.ldres = res.shape[-1] if res is not None else 0
     d.out = out.data_ptr(); d.ldout = out_ld
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    key = f'{B}x{H}x{W}x{cin}/{ldin}->{cw.cout}/{out_ld} k{cw.kh}s{cw.stride}p{cw.pad} r{int(res is not None)}{int(relu_in)}{int(relu_out)}'
+    plan = _load_plans().get(key) or _tuned_now.get(key)
+    if plan is None:
+        plan = (0, 0)
+        if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
+            plan = _tune_conv(lib, d, x.device)
+        _tuned_now[key] = plan
+    d.plan_tile, d.plan_splitk = plan
     need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(need, x.device, 'conv') if need else None
     ev = _prof_begin()
