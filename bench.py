@@ -113,18 +113,17 @@ def run_gpu(args, device, rank, world):
         out_masks.append(one_step(args.warmup + i))
     torch.cuda.synchronize(device); barrier(device)
     elapsed = time.perf_counter() - t0
-    # ---- per-kernel durations: HIP events (torch events on the launch stream) around every conv / affinity launch.
-    # The timed region replays captured HIP graphs, which cannot carry timing events, so the same frames are
-    # replayed eagerly here (identical kernels, shapes and launch parameters); profiles/ holds the rocprofv3
-    # kernel trace of the timed command itself.
+    # ---- per-kernel durations, measured live with HIP events on the launch stream: the launches of ONE frame are
+    # recorded in an eager pass (the timed region replays captured HIP graphs, which cannot carry timing events) and
+    # every distinct launch is then timed back to back (10 repetitions between two events).  profiles/ holds the
+    # rocprofv3 kernel trace of the timed command itself.
     prof, prof_frames = {}, 0
     if rank == 0:
-        prof_frames = min(args.steps, 20)
-        ops.PROFILE = {}
-        for i in range(prof_frames):
-            one_step(args.warmup + args.steps + i)
-        prof = ops.collect_profile()
-        ops.PROFILE = None
+        ops.RECORD = []
+        one_step(args.warmup + args.steps)
+        records, ops.RECORD = ops.RECORD, None
+        prof = ops.time_recorded(records, reps=10)
+        prof_frames = 1
     return dict(elapsed=elapsed, preload_s=preload_s, prof=prof, prof_frames=prof_frames, masks=out_masks, core=core,
                 frames=frames, masks_in=masks, sd=sd, n_query=n_query)
 
@@ -205,10 +204,10 @@ def main():
             'config': {'workload': 'B32: synthetic 480x854 clip, 1 object, 32 permanent memory frames (N=51840), '
                                    'mem_every=1e9, step()+argmax per frame, conditioned synthetic weights',
                        'replica_streams': world, 'top_k': TOPK, 'parallelism': f'{world} independent streams, no collectives'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_mfma_kernel (implicit-GEMM conv, fp32 MFMA)',
+            'roofline': {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel (implicit GEMM / Winograd-domain GEMM, fp32 MFMA) + transforms',
                          'achieved': conv_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (conv_tflops / PEAK_FP32_MFMA_TFLOPS) if conv_tflops else None, 'traffic': None,
-                         'measured': 'HIP events around each launch, eager replay of the timed frames (the timed region itself replays HIP graphs)',
+                         'measured': 'HIP events, each distinct launch of one frame timed over 10 back-to-back repetitions (includes the Winograd transform kernels of a convolution call)',
                          'launches_per_frame': conv['launches'] / max(res['prof_frames'], 1),
                          'kernel_ms_per_frame': conv['ms'] / max(res['prof_frames'], 1),
                          'algorithmic_gflop_per_frame': conv['flop'] / 1e9 / max(res['prof_frames'], 1)},

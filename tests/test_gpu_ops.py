@@ -85,6 +85,27 @@ def test_conv2d(case):
     close(nchw(out), ref, rtol=2e-4, atol=5e-5, msg=f'conv {case}')
 
 
+@pytest.mark.parametrize('plan', [(1, 1), (2, 2), (3, 4), (4, 1), (5, 3), (6, 2), (7, 1), (9, 1), (10, 1), (12, 1)])
+@pytest.mark.parametrize('shape', [(1, 30, 54, 256, 128), (2, 15, 27, 64, 96), (1, 17, 23, 32, 64)])
+def test_conv2d_every_plan(plan, shape):
+    """Every tile / split-K / Winograd plan the autotuner may pick computes the same 3x3 convolution."""
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    B, H, W, Cin, Cout = shape
+    gen = g_(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * (1.0 / (Cin * 9)) ** 0.5
+    shift = torch.randn(Cout, generator=gen) * 0.1
+    scale = torch.rand(Cout, generator=gen) * 0.5 + 0.75
+    res = torch.randn(B, Cout, H, W, generator=gen)
+    ref = F.relu(F.conv2d(F.relu(x), w, None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    cw = ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda(), 1, 1)
+    assert cw.wu is not None
+    out = ops.conv2d(nhwc(x), cw, res=nhwc(res), relu_in=True, relu_out=True, plan=plan)
+    torch.cuda.synchronize()
+    close(nchw(out), ref, rtol=2e-4, atol=5e-5, msg=f'conv plan {plan} {shape}')
+
+
 def test_conv2d_into_channel_slice_and_strided_input():
     """ldin / ldout: read a channel slice of a wider buffer and write into the middle of a concat buffer."""
     from xmem2_amd import ops

@@ -28,6 +28,8 @@ struct ConvArgs {
     int relu_in, relu_out;
     int nk, splitk, kt_per_split;
     int tiles_m, tiles_n;
+    int raw;                                   // 1: store the bare accumulator (Winograd-domain GEMM)
+    long in_gstride, w_gstride, out_gstride;   // blockIdx.y = group (the 16 Winograd tile positions), floats
 };
 
 template <int BM, int BN, int TM, int TN, int BK, bool GENERIC>
@@ -56,6 +58,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     }
     const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* __restrict__ gin = p.in + (size_t)blockIdx.y * p.in_gstride;
+    const float* __restrict__ gw = p.w + (size_t)blockIdx.y * p.w_gstride;
+    float* __restrict__ gout = p.out + (size_t)blockIdx.y * p.out_gstride;
 
     int a_ih0[RA], a_iw0[RA], a_pix[RA];
 #pragma unroll
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                 const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const long off = (long)(a_pix[i] + ih * p.W + iw) * p.ldin + c0 + c4 * 4;
-                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.in + off) : zero;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(gin + off) : zero;
             }
         } else {
             const int k = k0 + c4 * 4;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                 const bool ok = kok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const long off = (long)(a_pix[i] + ih * p.W + iw) * p.ldin + c0;
-                ra[i] = ok ? *reinterpret_cast<const f32x4*>(p.in + off) : zero;
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(gin + off) : zero;
             }
         }
         if (p.relu_in) {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         for (int i = 0; i < RB; ++i) {
             const int n = n0 + lrow + RPP * i;
             const bool ok = n < p.Cout && kb < p.K;
-            rb[i] = ok ? *reinterpret_cast<const f32x4*>(p.w + (size_t)n * p.K + kb) : zero;
+            rb[i] = ok ? *reinterpret_cast<const f32x4*>(gw + (size_t)n * p.K + kb) : zero;
         }
     };
     auto store_tile = [&](int buf) {
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         const int n = n0 + wn * 32 * TN + j * 32 + l31;
         if (n >= p.Cout) continue;
         float sc = 1.f, sh = 0.f;
-        if (p.splitk == 1) { sc = p.scale[n]; sh = p.shift[n]; }
+        if (p.splitk == 1 && !p.raw) { sc = p.scale[n]; sh = p.shift[n]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -180,11 +185,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= p.M) continue;
                 float v = acc[i][j][r];
-                if (p.splitk == 1) {
+                if (p.raw) {
+                    gout[(size_t)m * p.ldout + n] = v;
+                } else if (p.splitk == 1) {
                     v = v * sc + sh;
                     if (p.res) v += p.res[(size_t)m * p.ldres + n];
                     if (p.relu_out) v = fmaxf(v, 0.f);
-                    p.out[(size_t)m * p.ldout + n] = v;
+                    gout[(size_t)m * p.ldout + n] = v;
                 } else {
                     p.partial[((size_t)blockIdx.z * p.M + m) * p.Cout + n] = v;
                 }
@@ -241,11 +248,115 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions (85 % of the network's FLOPs):
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      (Lavin & Gray) - 16 multiplies per 2x2 outputs instead of 36.
+// The element-wise product over channels is 16 independent GEMMs [tiles x Cin] x [Cin x Cout] that run on the same
+// MFMA kernel (blockIdx.y = tile position), between two HBM-bound transform kernels.  All fp32.
+// ----------------------------------------------------------------------------------------------
+__global__ void wino_input_kernel(const float* __restrict__ in, int ldin, int B, int H, int W, int C, int th, int tw,
+                                  int relu_in, float* __restrict__ V) {
+    const int C4 = C >> 2;
+    const size_t P = (size_t)B * th * tw;
+    const size_t total = P * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t t = e / C4;
+        const int tx = (int)(t % tw); size_t r = t / tw;
+        const int ty = (int)(r % th);
+        const int b = (int)(r / th);
+        f32x4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = 2 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = 2 * tx - 1 + j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * ldin + c4 * 4);
+                    if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                d[i][j] = v;
+            }
+        }
+        f32x4 u[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // B^T d (rows)
+            u[0][j] = d[0][j] - d[2][j];
+            u[1][j] = d[1][j] + d[2][j];
+            u[2][j] = d[2][j] - d[1][j];
+            u[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {          // (B^T d) B (columns)
+            const f32x4 v0 = u[i][0] - u[i][2], v1 = u[i][1] + u[i][2], v2 = u[i][2] - u[i][1], v3 = u[i][1] - u[i][3];
+            float* o = V + ((size_t)(i * 4) * P + t) * C + c4 * 4;
+            *reinterpret_cast<f32x4*>(o) = v0;
+            *reinterpret_cast<f32x4*>(o + P * C) = v1;
+            *reinterpret_cast<f32x4*>(o + 2 * P * C) = v2;
+            *reinterpret_cast<f32x4*>(o + 3 * P * C) = v3;
+        }
+    }
+}
+
+__global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, int Wo, int Cout, int th, int tw,
+                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ res, int ldres, int relu_out, float* __restrict__ out, int ldout) {
+    const int N4 = Cout >> 2;
+    const size_t P = (size_t)B * th * tw;
+    const size_t total = P * N4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n4 = (int)(e % N4);
+        size_t t = e / N4;
+        const int tx = (int)(t % tw); size_t r = t / tw;
+        const int ty = (int)(r % th);
+        const int b = (int)(r / th);
+        f32x4 m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                m[i][j] = *reinterpret_cast<const f32x4*>(Mt + ((size_t)(i * 4 + j) * P + t) * Cout + n4 * 4);
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // A^T m
+            s0[j] = m[0][j] + m[1][j] + m[2][j];
+            s1[j] = m[1][j] - m[2][j] - m[3][j];
+        }
+        f32x4 y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n4 * 4);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int oh = 2 * ty + dy;
+            if (oh >= Ho) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ow = 2 * tx + dx;
+                if (ow >= Wo) continue;
+                const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
+                f32x4 v = y[dy][dx] * sc + sh;
+                if (res) v += *reinterpret_cast<const f32x4*>(res + pix * ldres + n4 * 4);
+                if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; };
+
+inline bool wino_ok(const xmem_conv_desc* d) {
+    return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
+           d->ldout % 4 == 0 && (!d->res || d->ldres % 4 == 0) && (((uintptr_t)d->out) & 15) == 0 && (!d->res || (((uintptr_t)d->res) & 15) == 0);
+}
 
 int validate(const xmem_conv_desc* d) {
     if (!d || !d->in || !d->w || !d->scale || !d->shift || !d->out) return XMEM_ERR_BAD_ARG;
@@ -254,7 +365,7 @@ int validate(const xmem_conv_desc* d) {
     if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
     if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
     if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
-    if (d->plan_tile < 0 || d->plan_tile > 6 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
+    if (d->plan_tile < 0 || d->plan_tile > 12 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
     return XMEM_OK;
 }
 
@@ -270,11 +381,19 @@ Plan make_plan(const xmem_conv_desc* d) {
     Plan pl;
     pl.bk = 32;
     pl.generic = false;
+    pl.wino = false;
     if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
     if (d->plan_tile > 0) {
         static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
-        pl.bm = cfg[d->plan_tile - 1][0]; pl.bn = cfg[d->plan_tile - 1][1]; pl.bk = cfg[d->plan_tile - 1][2];
+        int t = d->plan_tile;
+        if (t > 6 && wino_ok(d)) { pl.wino = true; }
+        if (t > 6) t -= 6;
+        pl.bm = cfg[t - 1][0]; pl.bn = cfg[t - 1][1]; pl.bk = cfg[t - 1][2];
+        if (pl.wino) {           // the GEMM runs per tile position: M = tiles, K = Cin, no split-K
+            pl.generic = (d->Cin % pl.bk) != 0; pl.nk = cdiv(d->Cin, pl.bk); pl.splitk = 1; pl.kt_per_split = pl.nk;
+            return pl;
+        }
     } else {
         // 256 CUs; two resident workgroups per CU is the sweet spot for the 128-wide tiles
         if (d->Cout > 64 && tiles(128, 128) >= 384) { pl.bm = 128; pl.bn = 128; }
@@ -302,23 +421,23 @@ Plan make_plan(const xmem_conv_desc* d) {
 }
 
 template <int BM, int BN, int TM, int TN, int BK, bool G>
-int launch_cfg(const ConvArgs& a, hipStream_t s) {
+int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
     }
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk);
+    dim3 grid(a.tiles_m * a.tiles_n, groups, a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return xmem_check_launch();
 }
 
 template <int BK, bool G>
-int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s) {
-    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s);
-    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s);
-    return launch_cfg<64, 64, 1, 1, BK, G>(a, s);
+int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s, int groups = 1) {
+    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s, groups);
+    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s, groups);
+    return launch_cfg<64, 64, 1, 1, BK, G>(a, s, groups);
 }
 
 }  // namespace
@@ -326,8 +445,9 @@ int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s) {
 extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
     if (validate(d) != XMEM_OK) return 0;
     Plan pl = make_plan(d);
-    if (pl.splitk == 1) return 0;
     int Ho, Wo; out_dims(d, Ho, Wo);
+    if (pl.wino) return (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * (d->Cin + d->Cout) * sizeof(float);
+    if (pl.splitk == 1) return 0;
     return (size_t)pl.splitk * d->B * Ho * Wo * d->Cout * sizeof(float);
 }
 
@@ -346,6 +466,36 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     a.relu_in = d->relu_in; a.relu_out = d->relu_out;
     a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
     a.tiles_m = pl.bm ? cdiv(a.M, pl.bm) : 0; a.tiles_n = pl.bn ? cdiv(a.Cout, pl.bn) : 0;
+    a.raw = 0; a.in_gstride = 0; a.w_gstride = 0; a.out_gstride = 0;
+    if (pl.wino) {
+        const int th = cdiv(Ho, 2), tw = cdiv(Wo, 2);
+        const size_t P = (size_t)d->B * th * tw;
+        const size_t need = (size_t)16 * P * (d->Cin + d->Cout) * sizeof(float);
+        if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
+        if (P > 0x7fffffff) return XMEM_ERR_UNSUPPORTED;
+        float* V = reinterpret_cast<float*>(workspace);
+        float* Mt = V + (size_t)16 * P * d->Cin;
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        size_t tot = P * (d->Cin / 4);
+        int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
+                           d->relu_in, V);
+        ConvArgs g = a;
+        g.in = V; g.w = d->w_winograd; g.out = Mt; g.res = nullptr; g.partial = nullptr;
+        g.B = 1; g.H = 1; g.W = (int)P; g.ldin = d->Cin; g.Ho = 1; g.Wo = (int)P; g.ldout = d->Cout; g.ldres = 0;
+        g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.K = d->Cin; g.M = (int)P; g.HoWo = (int)P;
+        g.relu_in = 0; g.relu_out = 0; g.nk = pl.nk; g.splitk = 1; g.kt_per_split = pl.nk;
+        g.tiles_m = cdiv(g.M, pl.bm); g.tiles_n = cdiv(g.Cout, pl.bn);
+        g.raw = 1; g.in_gstride = (long)P * d->Cin; g.w_gstride = (long)d->Cout * d->Cin; g.out_gstride = (long)P * d->Cout;
+        rc = (pl.bk == 64) ? (pl.generic ? launch_bk<64, true>(pl, g, s, 16) : launch_bk<64, false>(pl, g, s, 16))
+                           : (pl.generic ? launch_bk<32, true>(pl, g, s, 16) : launch_bk<32, false>(pl, g, s, 16));
+        if (rc != XMEM_OK) return rc;
+        tot = P * (d->Cout / 4);
+        blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wino_output_kernel, dim3(blocks), dim3(256), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
+                           d->res, d->ldres, d->relu_out, d->out, d->ldout);
+        return xmem_check_launch();
+    }
     if (pl.splitk > 1) {
         const size_t need = (size_t)pl.splitk * a.M * a.Cout * sizeof(float);
         if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;

@@ -209,7 +209,7 @@ class XMem:
         """Run `fn(*inputs)` eagerly, or capture it once per (name, shapes, flags) into a HIP graph with static
         input / output buffers and replay it.  Kernels are launched through ctypes on torch's current stream, which
         is the capturing stream inside torch.cuda.graph, so they are captured like any other launch."""
-        if not self.use_graphs or ops.PROFILE is not None:
+        if not self.use_graphs or ops.eager_only():
             return fn(*inputs)
         full_key = (name, key) + tuple(tuple(t.shape) if t is not None else None for t in inputs)
         st = self._stages.get(full_key)
@@ -323,7 +323,7 @@ class XMem:
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
         Once the decoder stage is captured this is its static input buffer (no copy before the replay)."""
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
-        if self.use_graphs and ops.PROFILE is None:
+        if self.use_graphs and not ops.eager_only():
             for k, st in self._stages.items():
                 if k[0] == 'segment' and tuple(st[1][3].shape) == shape:
                     return st[1][3]
@@ -336,7 +336,7 @@ class XMem:
         out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out)), [f16, f8, f4, cat16, hidden],
                               lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out),
                               alias=(0, 1, 2) if self._is_stage_output(f16) else ())
-        if self.use_graphs and ops.PROFILE is None:
+        if self.use_graphs and not ops.eager_only():
             new_hidden, prob, prob_padded = out              # hidden / prob outlive the stage's static buffers
             return (new_hidden.clone() if new_hidden is not None else None), prob.clone(), prob_padded
         return out

@@ -14,37 +14,40 @@ from . import _lib
 from ._lib import ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_ptr
 
 _workspaces = {}
+_retired = []
 
-# Optional live kernel timing for bench.py: PROFILE = {} enables HIP events (torch events record on the current
-# stream, which is the stream every kernel here is launched on) around the conv and affinity launches.
-PROFILE = None
-_events = []
-
-
-def _prof_begin():
-    if PROFILE is None:
-        return None
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    return e
+# Optional live kernel timing for bench.py.  RECORD = [] makes conv2d / affinity_topk append a re-launchable
+# closure for every call of one (eager) frame; time_recorded() then times each distinct launch back to back between
+# two HIP events (torch events record on the current stream, which is the stream every kernel here is launched on).
+RECORD = None
+PROFILE = None          # kept for compatibility: any non-None value also forces the eager (non-graph) path
 
 
-def _prof_end(kind, start, flop):
-    if start is None:
-        return
-    e = torch.cuda.Event(enable_timing=True)
-    e.record()
-    _events.append((kind, start, e, flop))
+def eager_only():
+    return RECORD is not None or PROFILE is not None
 
 
-def collect_profile():
-    """Synchronise and fold the recorded events: {kind: {ms, flop, launches}}."""
-    torch.cuda.synchronize()
+def time_recorded(records, reps=10):
+    """{kind: {ms, flop, launches}} for ONE frame: sum over the frame's launches of the average duration of that
+    launch (measured over `reps` back-to-back repetitions)."""
+    groups = {}
+    for kind, key, flop, fn, keep in records:
+        g = groups.setdefault((kind, key), [0, flop, fn, keep])
+        g[0] += 1
     out = {}
-    for kind, a, b, flop in _events:
+    for (kind, key), (count, flop, fn, keep) in groups.items():
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
         d = out.setdefault(kind, dict(ms=0.0, flop=0.0, launches=0))
-        d['ms'] += a.elapsed_time(b); d['flop'] += flop; d['launches'] += 1
-    _events.clear()
+        d['ms'] += e0.elapsed_time(e1) / reps * count
+        d['flop'] += flop * count
+        d['launches'] += count
     return out
 
 
@@ -53,7 +56,10 @@ def workspace(nbytes, device, tag='default'):
     key = (str(device), tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _retired.append(buf)        # captured HIP graphs may still hold the old pointer: never free it
+        grow = max(int(nbytes), 2 * (buf.numel() if buf is not None else 0), 1 << 20)
+        buf = torch.empty(grow, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
 
@@ -68,13 +74,27 @@ def _req(t, name):
 
 class ConvWeights:
     """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
-    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true')
+    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu')
 
-    def __init__(self, w, scale, shift, stride, pad, cin_true=None):
+    def __init__(self, w, scale, shift, stride, pad, cin_true=None, winograd=True):
         self.w, self.scale, self.shift = w, scale, shift
         self.cout, self.kh, self.kw, self.cin = w.shape
         self.stride, self.pad = stride, pad
         self.cin_true = cin_true if cin_true is not None else self.cin     # un-padded Cin (algorithmic FLOPs)
+        self.wu = None
+        if winograd and self.kh == 3 and self.kw == 3 and stride == 1 and pad == 1 and self.cin % 32 == 0 \
+                and self.cout % 4 == 0 and self.cout >= 32:
+            self.wu = winograd_weights(w)
+
+
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def winograd_weights(w):
+    """[Cout][3][3][Cin] -> G g G^T as [16][Cout][Cin] (load-time, fp32; F(2x2,3x3) of Lavin & Gray)."""
+    g = _WINO_G.to(w.device)
+    u = torch.einsum('ia,nabc,jb->ijnc', g, w, g)
+    return u.reshape(16, w.shape[0], w.shape[3]).contiguous()
 
 
 # ---- convolution plans ---------------------------------------------------------------------------------------
@@ -115,12 +135,15 @@ def _tune_conv(lib, d, x_device):
     M, K = d.B * Ho * Wo, d.KH * d.KW * d.Cin
     best, best_t = (0, 0), None
     tiles = {1: (128, 128, 32), 2: (128, 64, 32), 3: (64, 64, 32), 4: (128, 128, 64), 5: (128, 64, 64), 6: (64, 64, 64)}
-    for tile, (bm, bn, bk) in tiles.items():
+    cands = list(tiles.items())
+    if d.w_winograd and d.ldout % 4 == 0 and (not d.res or d.ldres % 4 == 0):
+        cands += [(t + 6, cfg) for t, cfg in tiles.items()]
+    for tile, (bm, bn, bk) in cands:
         if bn == 128 and d.Cout <= 64:
             continue
         nt = -(-M // bm) * -(-d.Cout // bn)
         nk = -(-K // bk)
-        for sk in (1, 2, 3, 4, 6, 8, 12, 16):
+        for sk in ((1,) if tile > 6 else (1, 2, 3, 4, 6, 8, 12, 16)):
             if sk > 1 and (nt * sk > 2048 or nk // sk < 2):
                 continue
             if sk == 1 and nt < 48 and nk >= 16:
@@ -145,7 +168,7 @@ def _tune_conv(lib, d, x_device):
     return best
 
 
-def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None):
+def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None, plan=None):
     """x [B,H,W,C] NHWC (or any buffer whose pixel stride is `in_ld`) -> out [B,Ho,Wo,Cout]."""
     lib = load()
     _req(x, 'conv2d input')
@@ -169,8 +192,10 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.ldres = res.shape[-1] if res is not None else 0
     d.out = out.data_ptr(); d.ldout = out_ld
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    d.w_winograd = cw.wu.data_ptr() if cw.wu is not None else None
     key = f'{B}x{H}x{W}x{cin}/{ldin}->{cw.cout}/{out_ld} k{cw.kh}s{cw.stride}p{cw.pad} r{int(res is not None)}{int(relu_in)}{int(relu_out)}'
-    plan = _load_plans().get(key) or _tuned_now.get(key)
+    if plan is None:
+        plan = _load_plans().get(key) or _tuned_now.get(key)
     if plan is None:
         plan = (0, 0)
         if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
@@ -179,9 +204,10 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.plan_tile, d.plan_splitk = plan
     need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(need, x.device, 'conv') if need else None
-    ev = _prof_begin()
     check(lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()))
-    _prof_end('conv', ev, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true)
+    if RECORD is not None:
+        RECORD.append(('conv', key, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true,
+                       lambda: lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()), (x, out, res, cw, ws)))
     return out
 
 
@@ -350,10 +376,12 @@ def affinity_topk(segments, qk, qe, top_k, want_sim=False):
     sim = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device) if want_sim else None
     need = lib.xmem_affinity_topk_workspace_bytes(n_total, HW, top_k)
     ws = workspace(need, qk.device, 'affinity')
-    ev = _prof_begin()
     check(lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
                                  ptr(ws), need, stream_ptr()))
-    _prof_end('affinity', ev, 4.0 * ck * n_total * HW)
+    if RECORD is not None:
+        RECORD.append(('affinity', f'{n_total}x{HW}k{top_k}', 4.0 * ck * n_total * HW,
+                       lambda: lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
+                                                      ptr(ws), need, stream_ptr()), (segs, qk, qe, w, idx, sim, ws)))
     return w, idx, sim
 
 
