@@ -30,7 +30,7 @@
 #define AFF_STEP_ROWS 128  // rows per step (4 waves)
 #define AFF_MAXU 4         // candidate entries per lane during a re-rank (cap <= 256)
 #define AFF_OUTCAP 64      // candidates a (split, query) hands to the merge kernel
-#define AFF_BOUND_M 2      // survivors per lane and query in the bound pass
+#define AFF_BOUND_M 1      // survivors per lane and query in the bound pass
 #define AFF_BOUND_SLOTS (8 * AFF_BOUND_M)   // per (split, query): 4 waves x 2 half-waves x M
 
 typedef unsigned long long u64;
@@ -49,6 +49,7 @@ struct AffArgs {
     float sqrt_ck; int sqrt_is_pow2;
     u64* part_key; int* part_cnt;    // select pass output: [splits][HW][AFF_OUTCAP], [splits][HW]
     float* bound_part;               // bound pass output: [splits][HW][AFF_BOUND_SLOTS]
+    int* ovf;                        // [query tiles] overflow flags of the optimistic select pass
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -90,15 +91,21 @@ __device__ __forceinline__ void rerank(u64* ck, int c, int top_k, float* tau_q, 
     if (lane == 0) *cnt_q = c < top_k ? c : top_k;
 }
 
-template <int CK, bool BOUND>
-__global__ __launch_bounds__(256) void affinity_kernel(AffArgs p) {
+// MODE 0: bound pass.  MODE 1: optimistic select (small candidate buffers, no re-rank, no barriers in the tile loop,
+// two workgroups per CU; a buffer overflow raises ovf[query tile]).  MODE 2: safe select (worst-case buffers +
+// re-rank valve); when p.ovf is set it only re-does query tiles whose optimistic pass overflowed.
+template <int CK, int MODE>
+__global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffArgs p) {
     static_assert(CK == 64, "kernel is specialised for C_k = 64");
+    constexpr bool BOUND = (MODE == 0);
+    constexpr bool SAFE = (MODE == 2);
+    if (SAFE && p.ovf && p.ovf[blockIdx.x] == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bq = smem;                               // [64][132]
     float* bsq = Bq + AFF_BQ * AFF_LDB;             // [64]
     float* tau = bsq + AFF_BQ;                      // [64]
     int* cnt = reinterpret_cast<int*>(tau + AFF_BQ);  // [64]
-    u64* cand = reinterpret_cast<u64*>(cnt + AFF_BQ);  // [64][cap]   (select pass only)
+    u64* cand = reinterpret_cast<u64*>(cnt + AFF_BQ + 4);  // [64][cap]   (select pass only); cnt[64..67]: flag + pad
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(AffArgs p) {
             tau[q] = (!BOUND && p.tau_init && qg < p.HW) ? nextafterf(p.tau_init[qg], -INFINITY) : -INFINITY;
             cnt[q] = 0;
         }
+        if (tid == 0) cnt[AFF_BQ] = 0;              // overflow-valve flag
     }
     __syncthreads();
 
@@ -172,21 +180,59 @@ __global__ __launch_bounds__(256) void affinity_kernel(AffArgs p) {
 #pragma unroll
         for (int j = 0; j < AFF_BOUND_M; ++j) top[sub][j] = -INFINITY;
 
-    issue_loads(t_begin + wave);
-    for (int tb = t_begin; tb < t_end; tb += 4) {
+    int* flag = cnt + AFF_BQ;                        // overflow-valve flag lives right after cnt[]
+    // sqrt(C_k) = 8 is a power of two, so ((x * ms) / sqrt(C_k)) == x * (ms * 0.125) bit for bit (memory_util.py:34-37)
+    static_assert(CK == 64, "scale folding assumes sqrt(C_k) is a power of two");
+    constexpr float inv_sqrt = 0.125f;
+    const float bs0 = bsq[l31], bs1 = bsq[32 + l31];
+    const bool q_ok0 = (q0 + l31) < p.HW, q_ok1 = (q0 + 32 + l31) < p.HW;
+
+    // ---- epilogue of one finished tile ---------------------------------------------------------------------
+    // acc already holds (sum - b_sq) (the accumulators start at -b_sq); msr = shrinkage / sqrt(C_k) per owned row.
+    // `best*` is the lane's running maximum of the tile (computed next to the following tile's MFMAs);
+    // only lanes whose maximum passes the bound walk their 16 values.
+    auto append_sub = [&](const f32x16& acc, const float* msr, int sub, float best, bool q_ok, int row0, int segn, int base) {
+        const int q = sub * 32 + l31;
+        const float my_tau = tau[q];
+        if (q_ok && best > my_tau) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float x = acc[r] * msr[r];
+                if (rr < segn && x > my_tau) {
+                    const int slot = atomicAdd(&cnt[q], 1);
+                    if (slot < p.cap) cand[(size_t)q * p.cap + slot] = pack_key(x, base + rr);
+                    if (SAFE) { if (slot >= p.limit) *flag = 1; }
+                    else if (slot >= p.cap) p.ovf[blockIdx.x] = 1;   // optimistic buffers exhausted: redo this query tile safely
+                }
+            }
+        }
+    };
+    auto bound_insert = [&](float v0, float v1) {      // branch-free insertion into the sorted survivors
+#pragma unroll
+        for (int j = 0; j < AFF_BOUND_M; ++j) {
+            const float h0 = fmaxf(top[0][j], v0); v0 = fminf(top[0][j], v0); top[0][j] = h0;
+            const float h1 = fmaxf(top[1][j], v1); v1 = fminf(top[1][j], v1); top[1][j] = h1;
+        }
+    };
+
+    // ---- one tile: MFMAs into (c0, c1) while the PREVIOUS tile (p0, p1) is filtered on the VALU ------------
+    struct TileMeta { int row0, segn, base; bool have, full; };
+    float msrA[16], msrB[16];
+    auto run_tile = [&](f32x16& c0, f32x16& c1, float* cmsr, TileMeta& cm,
+                        const f32x16& p0, const f32x16& p1, const float* pmsr, const TileMeta& pm, int tb) {
         f32x4 a[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) a[t] = an[t];
         const float ms_mine = msn;
-        const bool active = n_active;
-        const int segn = n_segn, base = n_base, row0 = n_row0;
+        cm.have = n_active; cm.row0 = n_row0; cm.segn = n_segn; cm.base = n_base;
+        cm.full = n_active && (n_row0 + AFF_ROWS <= n_segn);
         issue_loads(tb + 4 + wave);               // next tile's rows in flight under the MFMAs
-
-        if (active) {
-            // two independent accumulator chains (the two 32-query sub-tiles) keep the matrix pipe busy
-            f32x16 acc0, acc1;
+        const bool pfast = pm.have && pm.full;    // full previous tile: its filter runs inside the MFMA loop
+        float best0 = -INFINITY, best1 = -INFINITY;
+        if (cm.have) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { c0[r] = -bs0; c1[r] = -bs1; }
             const float* bq0 = Bq + l31 * AFF_LDB + lh * 4;
             const float* bq1 = bq0 + 32 * AFF_LDB;
 #pragma unroll
@@ -199,54 +245,65 @@ __global__ __launch_bounds__(256) void affinity_kernel(AffArgs p) {
                 for (int j = 0; j < 4; ++j) {
                     const float x = a[t][j];
                     const float xx = x * x;
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo0[j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo1[j], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi0[j], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi1[j], acc1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo0[j], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo1[j], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi0[j], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi1[j], c1, 0, 0, 0);
                 }
-            }
-            // shrinkage of the 16 rows this lane owns; ((x*ms)/sqrt(Ck)) == x*(ms/sqrt(Ck)) exactly when sqrt(Ck) = 2^j
-            float msr[16];
+                if (pfast) {                      // two rows of the previous tile per k-group: pure VALU, no branches
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m = __shfl(ms_mine, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
-                msr[r] = p.sqrt_is_pow2 ? m / p.sqrt_ck : m;
-            }
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int q = sub * 32 + l31;
-                const float my_tau = tau[q], bs = bsq[q];
-                const bool q_ok = (q0 + q) < p.HW;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float x = ((sub ? acc1[r] : acc0[r]) - bs) * msr[r];
-                    float v = p.sqrt_is_pow2 ? x : x / p.sqrt_ck;
-                    const int rr = row0 + rl;
-                    if (BOUND) {
-                        v = (rr < segn) ? v : -INFINITY;
-#pragma unroll
-                        for (int j = 0; j < AFF_BOUND_M; ++j) {       // branch-free insertion into the sorted survivors
-                            const float hi = fmaxf(top[sub][j], v);
-                            v = fminf(top[sub][j], v);
-                            top[sub][j] = hi;
-                        }
-                    } else if (q_ok && rr < segn && v > my_tau) {
-                        const int slot = atomicAdd(&cnt[q], 1);
-                        if (slot < p.cap) cand[(size_t)q * p.cap + slot] = pack_key(v, base + rr);
+                    for (int r = 2 * t; r < 2 * t + 2; ++r) {
+                        float x0 = p0[r] * pmsr[r], x1 = p1[r] * pmsr[r];
+                        if (BOUND) bound_insert(x0, x1);
+                        else { best0 = fmaxf(best0, x0); best1 = fmaxf(best1, x1); }
                     }
                 }
             }
-        }
-        if (!BOUND) {
-            __syncthreads();
-            for (int q = wave; q < AFF_BQ; q += 4) {
-                const int c = cnt[q];
-                if (c > p.limit) rerank(cand + (size_t)q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane);
+            // shrinkage of the 16 rows this lane owns; ((x*ms)/sqrt(Ck)) == x*(ms/sqrt(Ck)) exactly when sqrt(Ck) = 2^j
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m = __shfl(ms_mine, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+                cmsr[r] = m * inv_sqrt;
             }
-            __syncthreads();
         }
+        if (pm.have && !(pfast && cm.have)) {     // ragged previous tile, or nothing to hide it under: plain loop
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = pm.row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float x0 = p0[r] * pmsr[r], x1 = p1[r] * pmsr[r];
+                x0 = rr < pm.segn ? x0 : -INFINITY; x1 = rr < pm.segn ? x1 : -INFINITY;
+                if (BOUND) bound_insert(x0, x1);
+                else { best0 = fmaxf(best0, x0); best1 = fmaxf(best1, x1); }
+            }
+        }
+        if (!BOUND && pm.have) {
+            append_sub(p0, pmsr, 0, best0, q_ok0, pm.row0, pm.segn, pm.base);
+            append_sub(p1, pmsr, 1, best1, q_ok1, pm.row0, pm.segn, pm.base);
+        }
+        if (SAFE) {
+            __syncthreads();
+            if (*flag) {                          // overflow valve: a buffer passed `limit` entries (never with a valid bound)
+                for (int q = wave; q < AFF_BQ; q += 4) {
+                    const int c = cnt[q];
+                    if (c > p.limit) rerank(cand + (size_t)q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane);
+                }
+                __syncthreads();
+                if (tid == 0) *flag = 0;
+                __syncthreads();
+            }
+        }
+    };
+
+    f32x16 accA0, accA1, accB0, accB1;
+    TileMeta mA = {0, 0, 0, false, false}, mB = {0, 0, 0, false, false};
+    issue_loads(t_begin + wave);
+    // steps are processed in pairs so that the accumulator sets swap roles without register copies; one extra
+    // (empty) step flushes the filter of the last tile.
+    for (int tb = t_begin; tb < t_end + 4; tb += 8) {
+        run_tile(accA0, accA1, msrA, mA, accB0, accB1, msrB, mB, tb);
+        run_tile(accB0, accB1, msrB, mB, accA0, accA1, msrA, mA, tb + 4);
     }
+    if (!BOUND) __syncthreads();
 
     if (BOUND) {
 #pragma unroll
@@ -265,7 +322,8 @@ __global__ __launch_bounds__(256) void affinity_kernel(AffArgs p) {
         const int qg = q0 + q;
         if (qg >= p.HW) continue;
         int c = cnt[q];
-        if (c > AFF_OUTCAP) { rerank(cand + (size_t)q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane); c = min(c, p.top_k); }
+        if (SAFE) { if (c > AFF_OUTCAP) { rerank(cand + (size_t)q * p.cap, c, p.top_k, &tau[q], &cnt[q], lane); c = min(c, p.top_k); } }
+        else c = min(c, p.cap);                   // cap <= AFF_OUTCAP in the optimistic pass
         const size_t o = (size_t)split * p.HW + qg;
         if (lane == 0) p.part_cnt[o] = c;
         for (int s = lane; s < c; s += 64) p.part_key[o * AFF_OUTCAP + s] = cand[(size_t)q * p.cap + s];
@@ -367,23 +425,27 @@ AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound) {
     pl.splits = cdiv(sub_tiles, pl.tiles_per_split);
     pl.limit = top_k <= 96 ? 96 : (top_k + 7) / 8 * 8;      // re-rank when a buffer holds more than `limit` entries
     pl.cap = pl.limit + AFF_STEP_ROWS;
-    pl.lds = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ) * sizeof(float) + (bound ? 0 : (size_t)AFF_BQ * pl.cap * sizeof(u64));
+    pl.lds = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float) + (bound ? 0 : (size_t)AFF_BQ * pl.cap * sizeof(u64));
     return pl;
 }
+
+#define AFF_OPT_CAP 48     // optimistic candidate buffer (expected fill ~ R*k/splits = 6): 24.6 KB -> two workgroups per CU
+inline size_t opt_lds() { return ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float) + (size_t)AFF_BQ * AFF_OPT_CAP * sizeof(u64); }
 
 inline int bound_stride(int total_tiles) {
     // the bound pass samples every 4th 32-row tile (25 % extra MFMA work) once the memory is large enough
     return total_tiles >= 256 ? 4 : 1;
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, total; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, total; };
 WsLayout ws_layout(int HW) {
     WsLayout w;
     w.key_off = 0;
     w.cnt_off = align_up((size_t)64 * HW * AFF_OUTCAP * sizeof(u64), 256);
     w.bound_off = w.cnt_off + align_up((size_t)64 * HW * sizeof(int), 256);
     w.tau_off = w.bound_off + align_up((size_t)16 * HW * AFF_BOUND_SLOTS * sizeof(float), 256);
-    w.total = w.tau_off + align_up((size_t)HW * sizeof(float), 256);
+    w.ovf_off = w.tau_off + align_up((size_t)HW * sizeof(float), 256);
+    w.total = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
     return w;
 }
 }  // namespace
@@ -425,11 +487,12 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     int rc;
     const int R = bound_stride(tiles);
     a.tau_init = nullptr;
+    a.ovf = nullptr;
     if (R > 1) {
         AffPlan pa = aff_plan(cdiv(tiles, R), HW, top_k, true);
         a.cap = 0; a.limit = 0; a.splits = pa.splits; a.tiles_per_split = pa.tiles_per_split; a.sub_tiles = pa.sub_tiles;
         a.tile_stride = R;
-        hipLaunchKernelGGL((affinity_kernel<64, true>), dim3(cdiv(HW, AFF_BQ), pa.splits), dim3(256), pa.lds, s, a);
+        hipLaunchKernelGGL((affinity_kernel<64, 0>), dim3(cdiv(HW, AFF_BQ), pa.splits), dim3(256), pa.lds, s, a);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         const int T = pa.splits * AFF_BOUND_SLOTS;
         hipLaunchKernelGGL(affinity_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), (size_t)4 * T * sizeof(float), s,
@@ -438,9 +501,18 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
         a.tau_init = tau0;
     }
     AffPlan pl = aff_plan(tiles, HW, top_k, false);
-    a.cap = pl.cap; a.limit = pl.limit; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
+    a.limit = pl.limit; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
     a.tile_stride = 1;
-    auto kern = affinity_kernel<64, false>;
+    if (R > 1 && top_k <= AFF_OPT_CAP) {
+        // optimistic select with the bound in hand, then the safe kernel on the (normally zero) overflowed query tiles
+        a.ovf = reinterpret_cast<int*>(ws + wl.ovf_off);
+        if (hipMemsetAsync(a.ovf, 0, (size_t)cdiv(HW, AFF_BQ) * sizeof(int), s) != hipSuccess) return XMEM_ERR_LAUNCH;
+        a.cap = AFF_OPT_CAP;
+        hipLaunchKernelGGL((affinity_kernel<64, 1>), dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), opt_lds(), s, a);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    }
+    a.cap = pl.cap;
+    auto kern = affinity_kernel<64, 2>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
         return XMEM_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
