@@ -3,7 +3,8 @@
 
 Workload B32: synthetic 480x854 clip (pads to 480x864, HW=1620), 1 object, 32 annotated frames preloaded
 with put_to_permanent_memory, mem_every=1e9 so N stays 32*1620 = 51840; every timed step is
-encode_key -> match_memory -> segment -> resize/argmax -> uint8 mask on the host (run_on_video.py:106-113 timing).
+encode_key -> match_memory -> segment -> resize/argmax -> uint8 mask on the host (run_on_video.py:106-113 timing;
+the device->host copy of frame t is awaited after frame t+1 is enqueued, every mask is on the host before the clock stops).
 One process per GPU; ranks run independent replica streams (no data-path collective); rank 0 prints ONE JSON line.
 """
 import argparse
@@ -99,18 +100,24 @@ def run_gpu(args, device, rank, world):
     preload_s = time.perf_counter() - t0
     assert core.memory.permanent_work_mem.size == MEM_FRAMES * 1620
 
+    from xmem2_amd.run_on_video import AsyncMaskFetcher
+    fetcher = AsyncMaskFetcher()                      # uint8 masks reach the host one frame behind the GPU (as run_on_video)
+
     def one_step(i):
         prob = core.step(fr[MEM_FRAMES + (i % n_query)], None, None)
-        return ops.argmax_u8(prob).cpu()             # uint8 mask on the host, as _post_process (synchronises)
+        return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
 
     for i in range(args.warmup):
         one_step(i)
+    fetcher.drain()
     # ---- timed region: exactly `steps` frames, barrier + device sync on both sides --------------------------
     barrier(device); torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     out_masks = []
     for i in range(args.steps):
-        out_masks.append(one_step(args.warmup + i))
+        out_masks += one_step(args.warmup + i)
+    out_masks += [m for _, m in fetcher.drain()]      # every mask of the timed steps is on the host before the clock stops
+    assert len(out_masks) == args.steps
     torch.cuda.synchronize(device); barrier(device)
     elapsed = time.perf_counter() - t0
     # ---- per-kernel durations, measured live with HIP events on the launch stream: the launches of ONE frame are
@@ -121,6 +128,7 @@ def run_gpu(args, device, rank, world):
     if rank == 0:
         ops.RECORD = []
         one_step(args.warmup + args.steps)
+        fetcher.drain()
         records, ops.RECORD = ops.RECORD, None
         prof = ops.time_recorded(records, reps=10)
         prof_frames = 1

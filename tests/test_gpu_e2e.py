@@ -3,6 +3,7 @@
 Acceptance: IoU >= 0.999 per clip against the reference's argmax masks and argmax identical wherever
 the reference's own top-2 probability margin exceeds its thread-noise floor."""
 import ast
+import os
 
 import numpy as np
 import pytest
@@ -88,3 +89,33 @@ def test_step_flags_and_key_outputs(hip_net):
     assert p2.shape == (3, 96, 130) and bool(torch.isfinite(p2).all())
     assert float((p2.sum(0) - 1).abs().max()) < 1e-5
     assert core.memory.temporary_work_mem.size == 6 * 9
+
+
+def test_run_on_video_surface(tmp_path):
+    """The reference's run_on_video call shape end to end on files: stats DataFrame, mask PNGs, IoU column."""
+    from PIL import Image
+    from xmem2_amd.run_on_video import run_on_video
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    imgs, msks, out = tmp_path / 'JPEGImages', tmp_path / 'Annotations', tmp_path / 'out'
+    imgs.mkdir(); msks.mkdir()
+    t, hw = 7, (96, 128)
+    frames = synthetic_frames(t, *hw); masks = synthetic_masks(t, 2, *hw)
+    palette = [0, 0, 0, 200, 0, 0, 0, 200, 0] + [0] * (256 * 3 - 9)
+    for i in range(t):
+        rgb = np.clip((frames[i].transpose(1, 2, 0) * 0.229 + 0.45) * 255, 0, 255).astype(np.uint8)
+        Image.fromarray(rgb).save(imgs / f'frame_{i:06d}.png')
+        idx = (masks[i, 0] * 1 + masks[i, 1] * 2).astype(np.uint8)
+        im = Image.fromarray(idx, mode='P'); im.putpalette(palette); im.save(msks / f'frame_{i:06d}.png')
+    stats = run_on_video(str(imgs), str(msks), str(out), frames_with_masks=[0, 4], compute_iou=True, print_progress=False,
+                         overwrite_config={'model': None, 'size': -1, 'mem_every': 2}, save_overlay=True)
+    assert list(stats['frame']) == [f'frame_{i:06d}.png' for i in range(t)]
+    assert list(stats['mask_provided']) == [i in (0, 4) for i in range(t)]
+    assert all(stats['iou'][i] == -1 for i in (0, 4)) and all(0.0 <= stats['iou'][i] <= 1.0 for i in (1, 2, 3, 5, 6))
+    written = sorted(os.listdir(out / 'masks'))
+    assert written == [f'frame_{i:06d}.png' for i in range(t)] and len(os.listdir(out / 'overlay')) == t
+    # a frame whose mask was given comes back as that mask
+    got = np.array(Image.open(out / 'masks' / 'frame_000000.png').convert('RGB'))
+    want = np.array(Image.open(msks / 'frame_000000.png').convert('RGB'))
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        run_on_video(str(imgs), str(msks), str(out), frames_with_masks=[], overwrite_config={'model': None, 'size': -1})

@@ -7,7 +7,8 @@ the first kernel call loads the library and fails loudly if it is missing (no CP
 """
 from .configuration import VIDEO_INFERENCE_CONFIG
 
-__all__ = ['VIDEO_INFERENCE_CONFIG', 'XMem', 'InferenceCore', 'MemoryManager', 'KeyValueMemoryStore', 'run_on_video']
+__all__ = ['VIDEO_INFERENCE_CONFIG', 'XMem', 'InferenceCore', 'MemoryManager', 'KeyValueMemoryStore']
+# the harness keeps the reference's module path: `from xmem2_amd.run_on_video import run_on_video`
 
 
 def __getattr__(name):
@@ -23,7 +24,4 @@ def __getattr__(name):
     if name == 'KeyValueMemoryStore':
         from .kv_memory_store import KeyValueMemoryStore
         return KeyValueMemoryStore
-    if name == 'run_on_video':
-        from .run_on_video import run_on_video
-        return run_on_video
     raise AttributeError(name)

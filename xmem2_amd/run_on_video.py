@@ -139,6 +139,52 @@ def _overlay(img, mask_rgb, alpha=0.5):
     return Image.composite(img, Image.fromarray(m), Image.fromarray(a, mode='L'))
 
 
+class AsyncMaskFetcher:
+    """Device->host delivery of the uint8 index masks one frame behind the GPU: the copy of frame t goes to pinned
+    memory on the compute stream and is waited for only after frame t+1 has been enqueued, so the GPU never idles
+    on the host round trip (the reference blocks on `.cpu()` every frame, run_on_video.py:170-172)."""
+
+    def __init__(self, depth=3):
+        self.depth = depth
+        self.slots = [None] * depth
+        self.pending = []          # (tag, host tensor, event)
+        self._n = 0
+
+    def submit(self, tag, mask_gpu):
+        i = self._n % self.depth
+        self._n += 1
+        buf = self.slots[i]
+        if buf is None or buf.shape != mask_gpu.shape:
+            buf = torch.empty(mask_gpu.shape, dtype=torch.uint8, pin_memory=True)
+            self.slots[i] = buf
+        buf.copy_(mask_gpu, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((tag, buf, ev))
+        ready = []
+        while len(self.pending) >= self.depth:      # keep at most depth-1 frames in flight
+            ready.append(self._pop())
+        return ready
+
+    def _pop(self):
+        tag, buf, ev = self.pending.pop(0)
+        ev.synchronize()
+        return tag, buf.numpy().copy()
+
+    def drain(self):
+        out = []
+        while self.pending:
+            out.append(self._pop())
+        return out
+
+
+def _post_process_gpu(sample, prob):
+    """run_on_video.py:165-170 on the device: resize to the original shape if needed, argmax over classes."""
+    if sample.need_resize and tuple(prob.shape[-2:]) != tuple(sample.shape):
+        prob = ops.resize_bilinear(prob, sample.shape)
+    return ops.argmax_u8(prob)
+
+
 def _post_process(sample, prob):
     """run_on_video.py:165-173: resize to the original shape if needed, argmax over classes, uint8 on the host."""
     if sample.need_resize and tuple(prob.shape[-2:]) != tuple(sample.shape):
@@ -203,6 +249,21 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
 
     stats, total_time = [], 0.0
     saver = _AsyncSaver(config['masks_out_path'], vid_reader.vid_name, image_saving_max_queue_size) if config['save_masks'] else None
+    fetcher = AsyncMaskFetcher()
+
+    def finish(tag, out_mask):                                       # host side of a frame whose mask has arrived
+        sample, had_mask = tag
+        stat = {'frame': sample.frame, 'mask_provided': had_mask}
+        if compute_iou:
+            gt = sample.mask
+            stat['iou'] = float(compute_array_iou(out_mask, gt)) if (gt is not None and not had_mask) else -1
+        stats.append(stat)
+        if saver is not None:
+            out_img = vid_reader.map_the_colors_back(Image.fromarray(mapper.remap_index_mask(out_mask)))
+            saver.save(out_img, 'masks', sample.frame[:-4] + '.png')
+            if save_overlay:
+                saver.save(_overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg')
+
     try:
         for ti in range(vid_length):
             sample = vid_reader[ti]
@@ -218,18 +279,15 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             a = perf_counter()
             prob = processor.step(rgb, msk, labels, end=(ti == vid_length - 1),
                                   manually_curated_masks=manually_curated_masks, do_not_add_mask_to_memory=skip_add)
-            out_mask = _post_process(sample, prob)                   # .cpu() synchronises the stream
+            done = fetcher.submit((sample, msk is not None), _post_process_gpu(sample, prob))
             total_time += perf_counter() - a
-            stat = {'frame': sample.frame, 'mask_provided': msk is not None}
-            if compute_iou:
-                gt = sample.mask
-                stat['iou'] = float(compute_array_iou(out_mask, gt)) if (gt is not None and msk is None) else -1
-            stats.append(stat)
-            if saver is not None:
-                out_img = vid_reader.map_the_colors_back(Image.fromarray(mapper.remap_index_mask(out_mask)))
-                saver.save(out_img, 'masks', sample.frame[:-4] + '.png')
-                if save_overlay:
-                    saver.save(_overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg')
+            for tag, out_mask in done:
+                finish(tag, out_mask)
+        a = perf_counter()
+        done = fetcher.drain()
+        total_time += perf_counter() - a
+        for tag, out_mask in done:
+            finish(tag, out_mask)
     finally:
         if saver is not None:
             saver.close()
