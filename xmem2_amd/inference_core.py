@@ -97,8 +97,10 @@ class InferenceCore:
         is_normal_update = (not self.deep_update_sync or not is_deep_update) and (not end)
 
         net, mem = self.network, self.memory
-        key, shrinkage, selection, f16, f8, f4 = net.encode_key_nhwc(
-            image4, need_sk=True, need_ek=(self.enable_long_term or need_segment))
+        enc = net.encode_key_nhwc(image4, need_sk=True, need_ek=(self.enable_long_term or need_segment),
+                                  with_skips=need_segment)
+        key, shrinkage, selection, f16, f8, f4 = enc[:6]
+        skips = enc[6] if len(enc) > 6 else None
         h, w = f16.shape[1], f16.shape[2]
 
         if disable_memory_updates:
@@ -114,7 +116,7 @@ class InferenceCore:
             mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024,
                                   disable_usage_updates=disable_memory_updates)
             new_hidden, prob, prob_padded = net.segment_nhwc(f16, f8, f4, cat16, hidden, hw, (self.pad[2], self.pad[0]),
-                                                             h_out=is_normal_update)
+                                                             h_out=is_normal_update, skips=skips)
             if is_normal_update:
                 mem.set_hidden(new_hidden)
 

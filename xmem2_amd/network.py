@@ -36,6 +36,11 @@ class XMem:
         # launch-bound stages (61 convolutions + ~40 small kernels per frame) are replayed as HIP graphs
         self.use_graphs = os.environ.get('XMEM_HIP_GRAPHS', '1') != '0'
         self._stages = {}
+        # the decoder's skip convolutions depend only on f8 / f4: inside the captured key-encoder graph they run on a
+        # forked stream next to the small-grid layer2 / layer3 kernels.  Measured neutral on MI355X (A/B on one box:
+        # 272 vs 273 fps), so it is off by default (XMEM_OVERLAP=1 enables it).
+        self.overlap_skips = os.environ.get('XMEM_OVERLAP', '0') != '0'
+        self._side = None
         weights = self.init_hyperparameters(config, model_path, map_location)
         if weights is not None:
             self.load_weights(weights, init_as_zero_if_needed=True)
@@ -231,8 +236,8 @@ class XMem:
         return static_out
 
     def _is_stage_output(self, t):
-        return any(any(o is not None and o.data_ptr() == t.data_ptr() for o in st[2]) for k, st in self._stages.items()
-                   if k[0] == 'key')
+        return any(any(isinstance(o, torch.Tensor) and o.data_ptr() == t.data_ptr() for o in st[2])
+                   for k, st in self._stages.items() if k[0] == 'key')
 
     # ---- building blocks (NHWC) -----------------------------------------------------------------
     def _bottleneck(self, x, p):
@@ -267,25 +272,49 @@ class XMem:
         return self._group_res(g, p + '.block2')
 
     # ---- hot path (NHWC) ------------------------------------------------------------------------
-    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True):
-        """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC).
+    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True, with_skips=False):
+        """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC)
+        [+ (skip8, skip4), the decoder's skip convolutions of f8 / f4, when with_skips and the graph path is active].
         With graphs on, the returned tensors are the stage's static buffers: valid until the next call."""
         self._need_weights()
-        return self._run_stage('key', (need_sk, need_ek), [image4],
-                               lambda im: self._encode_key_eager(im, need_sk, need_ek))
+        overlap = bool(with_skips and self.overlap_skips and self.use_graphs and not ops.eager_only() and image4.shape[0] == 1)
+        out = self._run_stage('key', (need_sk, need_ek, overlap), [image4],
+                              lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap))
+        if with_skips:
+            return out if overlap else tuple(out) + (None,)
+        return out[:6]
 
-    def _encode_key_eager(self, image4, need_sk, need_ek):
+    def _encode_key_eager(self, image4, need_sk, need_ek, overlap=False):
         W = self._w
         x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
         x = ops.maxpool3x3s2(x)
         f4 = self._stage(x, 'key_encoder.res2', 3, self._bottleneck)
+        skip4 = skip8 = None
+        main = torch.cuda.current_stream()
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=image4.device)
+            self._side.wait_stream(main)                       # fork: f4 is ready
+            ops._ws_suffix = '@side'
+            with torch.cuda.stream(self._side):
+                skip4 = ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
+            ops._ws_suffix = ''
         f8 = self._stage(f4, 'key_encoder.layer2', 4, self._bottleneck)
+        if overlap:
+            self._side.wait_stream(main)                       # f8 is ready
+            ops._ws_suffix = '@side'
+            with torch.cuda.stream(self._side):
+                skip8 = ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
+            ops._ws_suffix = ''
         f16 = self._stage(f8, 'key_encoder.layer3', 6, self._bottleneck)
         B, h, w, _ = f16.shape
         ld = _pad4(2 * self.key_dim + 1)
         proj = torch.empty((B, h, w, ld), dtype=torch.float32, device=f16.device)
         ops.conv2d(f16, W['key_proj'], out=proj, out_ld=ld)
         key, shr, sel = ops.key_post(proj, self.key_dim, need_sk, need_ek)
+        if overlap:
+            main.wait_stream(self._side)                       # join before the stage (and its graph capture) ends
+            return key, shr, sel, f16, f8, f4, (skip8, skip4)
         return key, shr, sel, f16, f8, f4
 
     def encode_value_nhwc(self, image4, f16, hidden, masks, is_deep_update=True):
@@ -329,19 +358,25 @@ class XMem:
                     return st[1][3]
         return torch.empty(shape, dtype=torch.float32, device=device)
 
-    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True):
+    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True, skips=None):
         """Decoder + soft aggregation.  cat16 holds the memory readout at channels [1024,1024+Cv).
         Returns new_hidden|None, prob [K+1,H,W] (unpadded), prob_padded [K+1,Hp,Wp]."""
         self._need_weights()
-        out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out)), [f16, f8, f4, cat16, hidden],
-                              lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out),
-                              alias=(0, 1, 2) if self._is_stage_output(f16) else ())
+        if skips is not None:
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True),
+                                  [f16, f8, f4, cat16, hidden, skips[0], skips[1]],
+                                  lambda a, b, c, d, e, s8, s4: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out, (s8, s4)),
+                                  alias=(0, 1, 2, 5, 6) if self._is_stage_output(f16) else ())
+        else:
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), False), [f16, f8, f4, cat16, hidden],
+                                  lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out),
+                                  alias=(0, 1, 2) if self._is_stage_output(f16) else ())
         if self.use_graphs and not ops.eager_only():
             new_hidden, prob, prob_padded = out              # hidden / prob outlive the stage's static buffers
             return (new_hidden.clone() if new_hidden is not None else None), prob.clone(), prob_padded
         return out
 
-    def _segment_eager(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out):
+    def _segment_eager(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out, skips=None):
         W = self._w
         K, h, w, _ = cat16.shape
         hd = self.hidden_dim
@@ -349,9 +384,9 @@ class XMem:
         if hd > 0:
             ops.copy_channels(hidden, cat16, 1024 + self.value_dim)
         g16 = self._fusion(cat16, 'decoder.fuser')
-        skip8 = ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
+        skip8 = skips[0] if skips is not None else ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
         g8 = self._group_res(ops.upsample2x_add(g16, skip8), 'decoder.up_16_8.out_conv')
-        skip4 = ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
+        skip4 = skips[1] if skips is not None else ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
         g4 = self._group_res(ops.upsample2x_add(g8, skip4), 'decoder.up_8_4.out_conv')
         logits = ops.conv2d(g4, W['decoder.pred'], relu_in=True)          # [K,4h,4w,1]
         new_hidden = None

@@ -15,6 +15,7 @@ from ._lib import ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_p
 
 _workspaces = {}
 _retired = []
+_ws_suffix = ''
 
 # Optional live kernel timing for bench.py.  RECORD = [] makes conv2d / affinity_topk append a re-launchable
 # closure for every call of one (eager) frame; time_recorded() then times each distinct launch back to back between
@@ -53,7 +54,7 @@ def time_recorded(records, reps=10):
 
 def workspace(nbytes, device, tag='default'):
     """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so reuse is safe."""
-    key = (str(device), tag)
+    key = (str(device), tag + _ws_suffix)      # kernels on a side stream get their own scratch
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
