@@ -61,7 +61,8 @@ typedef struct {
     float* out;         int ldout;
     int relu_in, relu_out;
     int plan_tile;      /* 0 = built-in heuristic; 1..6 = {128x128, 128x64, 64x64} x {BK 32, BK 64} (autotuner override);
-                           7..12 = the same GEMM tiles inside the Winograd F(2x2,3x3) path (needs w_winograd) */
+                           7..12 = the same GEMM tiles inside the Winograd F(2x2,3x3) path (needs w_winograd);
+                           13..15 = fused Winograd GEMM + output transform, tiles {128x64, 64x64, 64x128} */
     int plan_splitk;    /* 0 = heuristic; >0 = number of K splits */
     const float* w_winograd; /* optional [16][Cout][Cin]: G g G^T of the 3x3 filter (3x3 / stride 1 / pad 1 only) */
 } xmem_conv_desc;

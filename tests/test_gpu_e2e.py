@@ -119,3 +119,42 @@ def test_run_on_video_surface(tmp_path):
     assert np.array_equal(got, want)
     with pytest.raises(ValueError):
         run_on_video(str(imgs), str(msks), str(out), frames_with_masks=[], overwrite_config={'model': None, 'size': -1})
+
+
+def test_e2e_objects_appearing_later_vs_oracle(hip_net, ref_net):
+    """Three objects, the third annotated only at frame 6 (a second object group, YouTubeVOS style), default-like
+    schedule with consolidation: HIP path vs the oracle on the same frames."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    t, hw = 16, (128, 192)
+    cfg = base_config(mem_every=2, max_mid_term_frames=4, min_mid_term_frames=2, num_prototypes=32)
+    frames = T(synthetic_frames(t, *hw)); masks = T(synthetic_masks(t, 3, *hw))
+    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
+    mism, n_pix, worst = 0, 0, 0.0
+    for ti in range(t):
+        if ti == 0:
+            labels, mk = [1, 2], masks[ti, :2]
+        elif ti == 6:
+            labels, mk = [1, 2, 3], masks[ti]
+        else:
+            labels, mk = None, None
+        if labels is not None:
+            core.set_all_labels(labels); ref.set_all_labels(labels)
+        kw = dict(end=(ti == t - 1))
+        # only the NEW object carries a valid label at frame 6: the others keep their prediction (merge path)
+        vl = None if mk is None else ([1, 2] if ti == 0 else [3])
+        p = core.step(frames[ti].cuda(), mk.cuda() if mk is not None else None, vl, **kw)
+        q = ref.step(frames[ti], mk.clone() if mk is not None else None, vl, **kw)
+        assert p.shape == q.shape
+        a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
+        mism += int((a != b).sum()); n_pix += a.size
+        worst = max(worst, float((p.cpu() - q).abs().mean()))
+        m, rm = core.memory, ref.memory
+        assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == \
+               (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size), f'frame {ti}'
+        assert m.temporary_work_mem.num_groups == rm.temporary_work_mem.num_groups
+    print(f'objects-appearing-later: argmax mismatch {mism}/{n_pix}, worst mean |dp| {worst:.2e}')
+    assert mism / n_pix < 5e-4 and worst < 5e-4
+    assert core.memory.temporary_work_mem.num_groups == 2 and core.memory.long_mem.size > 0

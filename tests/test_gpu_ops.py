@@ -85,7 +85,8 @@ def test_conv2d(case):
     close(nchw(out), ref, rtol=2e-4, atol=5e-5, msg=f'conv {case}')
 
 
-@pytest.mark.parametrize('plan', [(1, 1), (2, 2), (3, 4), (4, 1), (5, 3), (6, 2), (7, 1), (9, 1), (10, 1), (12, 1)])
+@pytest.mark.parametrize('plan', [(1, 1), (2, 2), (3, 4), (4, 1), (5, 3), (6, 2), (7, 1), (9, 1), (10, 1), (12, 1),
+                                  (13, 1), (14, 1), (15, 1)])
 @pytest.mark.parametrize('shape', [(1, 30, 54, 256, 128), (2, 15, 27, 64, 96), (1, 17, 23, 32, 64)])
 def test_conv2d_every_plan(plan, shape):
     """Every tile / split-K / Winograd plan the autotuner may pick computes the same 3x3 convolution."""
@@ -430,3 +431,41 @@ def test_topk_1d_and_select_and_gather():
     close(ops.gather_rows(src.cuda(), pick.cuda()), src[pick.long()], 0, 0, 'gather')
     u, l = torch.rand(100, generator=gen), torch.rand(100, generator=gen) + 0.5
     close(ops.usage_ratio(u.cuda(), l.cuda()), u / l, 1e-6, 0, 'usage ratio')
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs 4 / 5 sizes: the oracle cannot materialise N x HW (13 GB / 136 GB), so a random subset of the
+# queries is checked exactly and size-independent properties are checked for all of them.
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,hw,nseg', [(921600, 3600, 3), (4177920, 8160, 2)], ids=['C4_720p_256frames', 'C5_1080p_512frames'])
+def test_affinity_large_memory(n, hw, nseg):
+    from xmem2_amd import ops
+    gen = torch.Generator(device='cuda').manual_seed(n)
+    mk = torch.randn(n, 64, generator=gen, device='cuda') * 0.9
+    ms = torch.rand(n, generator=gen, device='cuda') * 3 + 1
+    qk = torch.randn(hw, 64, generator=gen, device='cuda') * 0.9
+    qe = torch.rand(hw, 64, generator=gen, device='cuda') * 0.9 + 0.05
+    cuts = [0] + sorted(torch.randint(1, n, (nseg - 1,)).tolist()) + [n]
+    segs = [(mk[a:b], ms[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    w, idx, sims = ops.affinity_topk(segs, qk, qe, 30, want_sim=True)
+    torch.cuda.synchronize()
+    w, idx, sims = w.cpu(), idx.cpu().long(), sims.cpu()
+    assert float((w.sum(1) - 1).abs().max()) < 1e-5
+    assert bool((sims[:, :-1] >= sims[:, 1:]).all()), 'top-k not sorted'
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    assert all(len(set(idx[q].tolist())) == 30 for q in range(0, hw, 97))
+    pick = torch.randperm(hw)[:48]
+    mkc, msc = mk.cpu(), ms.cpu()
+    sim = R.get_similarity(mkc.t().unsqueeze(0), msc.view(1, 1, -1), qk.cpu()[pick].t().unsqueeze(0), qe.cpu()[pick].t().unsqueeze(0))
+    vals_ref, idx_ref = torch.topk(sim[0], 30, dim=0)
+    close(sims[pick], vals_ref.t(), 1e-4, 1e-4, 'large-N top-k values')
+    same = (torch.sort(idx[pick], 1)[0] == torch.sort(idx_ref.t(), 1)[0]).all(1).float().mean()
+    assert float(same) > 0.9, f'only {float(same):.2f} of the sampled queries have the identical index set'
+    # the readout stays sparse: k rows per query regardless of N
+    out = torch.zeros(1, hw, 512).cuda()
+    V = torch.randn(n, 512, device='cuda', generator=gen) if n < 2_000_000 else None
+    if V is not None:
+        ops.readout_sparse([[V[a:b] for a, b in zip(cuts[:-1], cuts[1:])]], w.cuda(), idx.int().cuda(), 512, out, 512, hw * 512)
+        q0 = int(pick[0])
+        ref = (w[q0].unsqueeze(1) * V[idx[q0].cuda()].cpu()).sum(0)
+        close(out[0, q0], ref, 1e-3, 1e-5, 'large-N readout')

@@ -346,12 +346,171 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
     }
 }
 
+// Fused Winograd-domain GEMM + output transform.  One workgroup owns a (tile-pixel block x Cout block) and walks all 16
+// tile positions xi = (i, j) as ONE long K loop of 16 * Cin/BK staged tiles: after each position the 32x32 accumulator
+// M_xi is folded into the four output-position accumulators  Y[a][b] += At[a][i] * At[b][j] * M_xi  (At entries are
+// 0 / +-1), so the [16][tiles][Cout] intermediate never exists and prologue / epilogue are amortised over a 16x deeper
+// loop than the per-position GEMMs.  A = V[xi][m][k] (from wino_input_kernel), B = U[xi][n][k] = (G g G^T).
+struct WinoArgs {
+    const float* V; const float* U; const float* scale; const float* shift; const float* res; float* out;
+    int P, Cin, Cout, B, Ho, Wo, th, tw, ldout, ldres, relu_out, nk, tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int TM, int TN, int BK>
+__global__ __launch_bounds__(256) void wino_fused_kernel(WinoArgs p) {
+    constexpr int WN = BN / (32 * TN);
+    constexpr int WM = BM / (32 * TM);
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int LDK = BK + 4;
+    constexpr int C4 = BK / 4;
+    constexpr int RPP = 256 / C4;
+    constexpr int RA = BM / RPP, RB = BN / RPP;
+    constexpr int BUF = (BM + BN) * LDK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lrow = tid / C4, c4 = tid % C4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const size_t vstride = (size_t)p.P * p.Cin, ustride = (size_t)p.Cout * p.Cin;
+    f32x4 ra[RA], rb[RB];
+    auto load_tile = [&](int it) {
+        const int xi = it / p.nk, kt = it - xi * p.nk;
+        const int k = kt * BK + c4 * 4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const float* va = p.V + (size_t)xi * vstride + k;
+        const float* ub = p.U + (size_t)xi * ustride + k;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + lrow + RPP * i;
+            ra[i] = (m < p.P && k < p.Cin) ? *reinterpret_cast<const f32x4*>(va + (size_t)m * p.Cin) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + lrow + RPP * i;
+            rb[i] = (n < p.Cout && k < p.Cin) ? *reinterpret_cast<const f32x4*>(ub + (size_t)n * p.Cin) : zero;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* As = smem + buf * BUF;
+        float* Bs = As + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * LDK + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * i) * LDK + c4 * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+    f32x16 y[4][TM][TN];                       // output positions (a, b) = (o >> 1, o & 1)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[o][i][j][r] = 0.f;
+        }
+
+    const int total = 16 * p.nk;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int kt_in_xi = 0, xi = 0;
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1;
+        const bool has_next = it + 1 < total;
+        if (has_next) load_tile(it + 1);
+        const float* As = smem + buf * BUF + (wm * 32 * TM + l31) * LDK + lh * 4;
+        const float* Bs = smem + buf * BUF + BM * LDK + (wn * 32 * TN + l31) * LDK + lh * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (++kt_in_xi == p.nk) {              // position finished: Y[a][b] += At[a][i] * At[b][j] * M_xi
+            const int wi = xi >> 2, wj = xi & 3;
+            // At = [1 1 1 0; 0 1 -1 -1]
+            const float a0 = (wi < 3) ? 1.f : 0.f, a1 = (wi == 0) ? 0.f : (wi == 1 ? 1.f : -1.f);
+            const float b0 = (wj < 3) ? 1.f : 0.f, b1 = (wj == 0) ? 0.f : (wj == 1 ? 1.f : -1.f);
+            const float c00 = a0 * b0, c01 = a0 * b1, c10 = a1 * b0, c11 = a1 * b1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        y[0][i][j][r] = fmaf(c00, v, y[0][i][j][r]);
+                        y[1][i][j][r] = fmaf(c01, v, y[1][i][j][r]);
+                        y[2][i][j][r] = fmaf(c10, v, y[2][i][j][r]);
+                        y[3][i][j][r] = fmaf(c11, v, y[3][i][j][r]);
+                        acc[i][j][r] = 0.f;
+                    }
+                }
+            kt_in_xi = 0; ++xi;
+        }
+        if (has_next) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane owns output channel n and 16 tile-pixels per 32x32 tile; each tile-pixel is 2x2 outputs
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * 32 * TN + j * 32 + l31;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale[n], sh = p.shift[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.P) continue;
+                const int tx = m % p.tw; const int t2 = m / p.tw;
+                const int ty = t2 % p.th; const int b = t2 / p.th;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int oh = 2 * ty + (o >> 1), ow = 2 * tx + (o & 1);
+                    if (oh >= p.Ho || ow >= p.Wo) continue;
+                    const size_t pix = ((size_t)b * p.Ho + oh) * p.Wo + ow;
+                    float v = y[o][i][j][r] * sc + sh;
+                    if (p.res) v += p.res[pix * p.ldres + n];
+                    if (p.relu_out) v = fmaxf(v, 0.f);
+                    p.out[pix * p.ldout + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; };
 
 inline bool wino_ok(const xmem_conv_desc* d) {
     return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
@@ -365,7 +524,7 @@ int validate(const xmem_conv_desc* d) {
     if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
     if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
     if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
-    if (d->plan_tile < 0 || d->plan_tile > 12 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
+    if (d->plan_tile < 0 || d->plan_tile > 15 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
     return XMEM_OK;
 }
 
@@ -382,11 +541,16 @@ Plan make_plan(const xmem_conv_desc* d) {
     pl.bk = 32;
     pl.generic = false;
     pl.wino = false;
+    pl.fused = 0;
     if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
     if (d->plan_tile > 0) {
         static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
         int t = d->plan_tile;
+        if (t > 12) {                      // 13..15: fused Winograd GEMM + output transform {128x64, 64x64, 64x128}, BK 32
+            if (wino_ok(d)) { pl.wino = true; pl.fused = t - 12; }
+            t = (t == 13) ? 2 : 3;         // fall back to a direct tile when Winograd is not applicable
+        }
         if (t > 6 && wino_ok(d)) { pl.wino = true; }
         if (t > 6) t -= 6;
         pl.bm = cfg[t - 1][0]; pl.bn = cfg[t - 1][1]; pl.bk = cfg[t - 1][2];
@@ -446,6 +610,7 @@ extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
     if (validate(d) != XMEM_OK) return 0;
     Plan pl = make_plan(d);
     int Ho, Wo; out_dims(d, Ho, Wo);
+    if (pl.wino && pl.fused) return (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cin * sizeof(float);
     if (pl.wino) return (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * (d->Cin + d->Cout) * sizeof(float);
     if (pl.splitk == 1) return 0;
     return (size_t)pl.splitk * d->B * Ho * Wo * d->Cout * sizeof(float);
@@ -470,7 +635,7 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     if (pl.wino) {
         const int th = cdiv(Ho, 2), tw = cdiv(Wo, 2);
         const size_t P = (size_t)d->B * th * tw;
-        const size_t need = (size_t)16 * P * (d->Cin + d->Cout) * sizeof(float);
+        const size_t need = (size_t)16 * P * (d->Cin + (pl.fused ? 0 : d->Cout)) * sizeof(float);
         if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
         if (P > 0x7fffffff) return XMEM_ERR_UNSUPPORTED;
         float* V = reinterpret_cast<float*>(workspace);
@@ -480,6 +645,20 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
                            d->relu_in, V);
+        if (pl.fused) {
+            WinoArgs wa;
+            wa.V = V; wa.U = d->w_winograd; wa.scale = d->scale; wa.shift = d->shift; wa.res = d->res; wa.out = d->out;
+            wa.P = (int)P; wa.Cin = d->Cin; wa.Cout = d->Cout; wa.B = d->B; wa.Ho = Ho; wa.Wo = Wo; wa.th = th; wa.tw = tw;
+            wa.ldout = d->ldout; wa.ldres = d->ldres; wa.relu_out = d->relu_out; wa.nk = cdiv(d->Cin, 32);
+            const int bm = pl.fused == 1 ? 128 : 64, bn = pl.fused == 3 ? 128 : 64;
+            wa.tiles_m = cdiv(wa.P, bm); wa.tiles_n = cdiv(wa.Cout, bn);
+            const size_t lds = 2 * (size_t)(bm + bn) * 36 * sizeof(float);
+            dim3 grid(wa.tiles_m * wa.tiles_n);
+            if (pl.fused == 1) hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 1, 32>), grid, dim3(256), lds, s, wa);
+            else if (pl.fused == 2) hipLaunchKernelGGL((wino_fused_kernel<64, 64, 1, 1, 32>), grid, dim3(256), lds, s, wa);
+            else hipLaunchKernelGGL((wino_fused_kernel<64, 128, 1, 2, 32>), grid, dim3(256), lds, s, wa);
+            return xmem_check_launch();
+        }
         ConvArgs g = a;
         g.in = V; g.w = d->w_winograd; g.out = Mt; g.res = nullptr; g.partial = nullptr;
         g.B = 1; g.H = 1; g.W = (int)P; g.ldin = d->Cin; g.Ho = 1; g.Wo = (int)P; g.ldout = d->Cout; g.ldres = 0;

@@ -139,8 +139,9 @@ def _tune_conv(lib, d, x_device):
     cands = list(tiles.items())
     if d.w_winograd and d.ldout % 4 == 0 and (not d.res or d.ldres % 4 == 0):
         cands += [(t + 6, cfg) for t, cfg in tiles.items()]
+        cands += [(13, (128, 64, 32)), (14, (64, 64, 32)), (15, (64, 128, 32))]
     for tile, (bm, bn, bk) in cands:
-        if bn == 128 and d.Cout <= 64:
+        if bn == 128 and d.Cout <= 64 and tile != 15:
             continue
         nt = -(-M // bm) * -(-d.Cout // bn)
         nk = -(-K // bk)
