@@ -371,11 +371,38 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
     int incl = my_c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    const int total = __shfl(incl, 63, 64);
+    int total = __shfl(incl, 63, 64);
     const int excl = incl - my_c;
     for (int s = 0; s < splits; ++s) {
         const int c = __shfl(my_c, s, 64), off = __shfl(excl, s, 64);
         if (lane < c) keys[off + lane] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + lane];
+    }
+    // pre-filter: the top_k-th largest of the 64 lane-local maxima is reached by >= top_k candidates, so everything
+    // below it can be dropped before the O(T^2/64) exact ranking (tames queries with several hundred survivors)
+    if (total > 96) {
+        u64 lmax = 0ull;
+        for (int e = lane; e < total; e += 64) { const u64 k = keys[e]; lmax = k > lmax ? k : lmax; }
+        int rk = 0;
+        for (int j = 0; j < 64; ++j) {
+            const unsigned lo = __shfl((unsigned)lmax, j, 64), hi = __shfl((unsigned)(lmax >> 32), j, 64);
+            const u64 o = ((u64)hi << 32) | lo;
+            rk += (o > lmax) || (o == lmax && j < lane);
+        }
+        const unsigned long long sel = __ballot(rk == top_k - 1);
+        const int src = sel ? __ffsll((long long)sel) - 1 : 0;
+        const unsigned tlo = __shfl((unsigned)lmax, src, 64), thi = __shfl((unsigned)(lmax >> 32), src, 64);
+        const u64 thr = sel ? (((u64)thi << 32) | tlo) : 0ull;
+        int nk = 0;
+        for (int b0 = 0; b0 < total; b0 += 64) {               // stable in-place compaction (pos <= e)
+            const int e = b0 + lane;
+            const u64 k = e < total ? keys[e] : 0ull;
+            const bool keep = e < total && k >= thr;
+            const unsigned long long m = __ballot(keep);
+            const int pos = nk + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep) keys[pos] = k;
+            nk += __popcll(m);
+        }
+        total = nk;
     }
     if (lane == 0) keys[total] = 0ull;                       // pad for the 2-wide reads below
     // rank by counting (keys are unique: the index is part of the key)
@@ -429,7 +456,7 @@ AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound) {
     return pl;
 }
 
-#define AFF_OPT_CAP 48     // optimistic candidate buffer (expected fill ~ R*k/splits = 6): 24.6 KB -> two workgroups per CU
+#define AFF_OPT_CAP 56     // optimistic candidate buffer (expected fill ~ R*k/splits = 6, observed max 39): 28.7 KB -> two workgroups per CU
 inline size_t opt_lds() { return ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float) + (size_t)AFF_BQ * AFF_OPT_CAP * sizeof(u64); }
 
 inline int bound_stride(int total_tiles) {
