@@ -35,6 +35,8 @@ def shard_videos(videos, lengths, rank, world):
 def _reduce(value, device, op):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
+    if dist.get_backend() != 'nccl':
+        device = torch.device('cpu')
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=op)
     return float(t.item())
@@ -51,7 +53,7 @@ def sum_over_ranks(value, device):
 
 def barrier(device):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier(device_ids=[device.index] if device.type == 'cuda' else None)
+        dist.barrier(device_ids=[device.index] if (device.type == 'cuda' and dist.get_backend() == 'nccl') else None)
 
 
 # ---- workload ------------------------------------------------------------------------------------------------
@@ -181,6 +183,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--cpu-frames', type=int, default=8, help='timed frames of the CPU baseline leg (rank 0, N=1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', help='control-plane backend for the timing barrier / max-reduce '
+                    '(nccl = RCCL; the data path has no collective)')
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -188,11 +192,14 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     res = run_gpu(args, device, rank, world)
     elapsed = max_over_ranks(res['elapsed'], device)
     total_frames = sum_over_ranks(args.steps, device)

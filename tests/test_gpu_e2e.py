@@ -158,3 +158,37 @@ def test_e2e_objects_appearing_later_vs_oracle(hip_net, ref_net):
     print(f'objects-appearing-later: argmax mismatch {mism}/{n_pix}, worst mean |dp| {worst:.2e}')
     assert mism / n_pix < 5e-4 and worst < 5e-4
     assert core.memory.temporary_work_mem.num_groups == 2 and core.memory.long_mem.size > 0
+
+
+@pytest.mark.parametrize('cfg_over,curated', [(dict(deep_update_every=3, mem_every=2), False),
+                                              (dict(deep_update_every=-1, mem_every=1000), True)])
+def test_update_schedules_vs_oracle(hip_net, ref_net, cfg_over, curated):
+    """Non-synchronised deep updates (deep_update_every >= 0) and manually_curated_masks (memory frames = annotated
+    frames only), frame by frame against the oracle; also update_config at run time."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    t, hw = 10, (96, 144)
+    cfg = base_config(**cfg_over)
+    frames = T(synthetic_frames(t, *hw)); masks = T(synthetic_masks(t, 1, *hw))
+    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
+    for c in (core, ref):
+        c.set_all_labels([1])
+    core.put_to_permanent_memory(frames[0].cuda(), masks[0].cuda())
+    ref.put_to_permanent_memory(frames[0], masks[0])
+    for ti in range(t):
+        mk = masks[ti] if ti in (0, 5) else None
+        kw = dict(end=(ti == t - 1), manually_curated_masks=curated, do_not_add_mask_to_memory=(ti == 0))
+        if ti == 7:
+            cfg2 = dict(cfg, mem_every=1, top_k=20)
+            core.update_config(cfg2); ref.update_config(cfg2)
+        p = core.step(frames[ti].cuda(), mk.cuda() if mk is not None else None, [1] if mk is not None else None, **kw)
+        q = ref.step(frames[ti], mk.clone() if mk is not None else None, [1] if mk is not None else None, **kw)
+        d = (p.cpu() - q).abs()
+        assert float(d.mean()) < 3e-4 and float((p.cpu().argmax(0) != q.argmax(0)).float().mean()) < 1e-3, f'frame {ti}'
+        m, rm = core.memory, ref.memory
+        assert (m.temporary_work_mem.size, m.permanent_work_mem.size) == (rm.temporary_work_mem.size, rm.permanent_work_mem.size)
+        hd = (m.get_hidden().permute(0, 3, 1, 2).cpu() - rm.get_hidden()[0]).abs()
+        assert float(hd.max()) < 5e-3, f'hidden state diverged at frame {ti}: {float(hd.max()):.2e}'
+    with pytest.raises(AssertionError):
+        core.update_config(dict(cfg, enable_long_term=False))
