@@ -107,6 +107,8 @@ def run_gpu(args, device, rank, world):
 
     def one_step(i):
         prob = core.step(fr[MEM_FRAMES + (i % n_query)], None, None)
+        if not args.no_prefetch:                     # key encoder of frame i+1 on the side stream, under frame i's decoder
+            core.prefetch_key(fr[MEM_FRAMES + ((i + 1) % n_query)])
         return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
 
     for i in range(args.warmup):
@@ -183,6 +185,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--cpu-frames', type=int, default=8, help='timed frames of the CPU baseline leg (rank 0, N=1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true', help='do not pipeline the next frame\'s key encoder')
     ap.add_argument('--dist-backend', default='nccl', help='control-plane backend for the timing barrier / max-reduce '
                     '(nccl = RCCL; the data path has no collective)')
     args = ap.parse_args()
@@ -218,7 +221,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'B32: synthetic 480x854 clip, 1 object, 32 permanent memory frames (N=51840), '
                                    'mem_every=1e9, step()+argmax per frame, conditioned synthetic weights',
-                       'replica_streams': world, 'top_k': TOPK, 'parallelism': f'{world} independent streams, no collectives'},
+                       'replica_streams': world, 'top_k': TOPK, 'frame_pipelining': (not args.no_prefetch), 'parallelism': f'{world} independent streams, no collectives'},
             'roofline': {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel (implicit GEMM / Winograd-domain GEMM, fp32 MFMA) + transforms',
                          'achieved': conv_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (conv_tflops / PEAK_FP32_MFMA_TFLOPS) if conv_tflops else None, 'traffic': None,

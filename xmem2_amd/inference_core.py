@@ -18,6 +18,12 @@ class InferenceCore:
         self._read_config(config)
         self.clear_memory()
         self.all_labels = None
+        # frame pipelining: prefetch_key() runs the key encoder of the NEXT frame on a side stream (own graph slot and
+        # scratch) while the current frame's readout / decoder occupy the main stream
+        self._side = None
+        self._pf = None
+        self._slot = 0
+        self._slot_done = {0: None, 1: None}
         # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
         if getattr(network, 'device', None) is not None and network.device.type == 'cuda':
             with torch.cuda.device(network.device):
@@ -79,12 +85,59 @@ class InferenceCore:
         key, shr, sel, f16, _, _ = self.network.encode_key_nhwc(image4, need_sk=True, need_ek=True)
         return tuple(v.clone() for v in self._key_views(key, shr, sel, f16.shape[1], f16.shape[2]))
 
+    def prefetch_key(self, image):
+        """Enqueue the key encoder for a FUTURE frame.  `image` (3 x H x W float32, CPU-pinned or device tensor that is
+        already complete) is returned as the device tensor to hand to the next `step()`; the call is a no-op hint
+        when graphs are off.  Not part of the reference surface: `step()` behaves identically without it."""
+        net = self.network
+        if not (getattr(net, 'use_graphs', False) and net.device.type == 'cuda') or ops.eager_only():
+            return image.to(net.device) if not image.is_cuda else image
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=net.device)
+        slot = self._slot ^ 1
+        if self._pf is not None:                       # an unused prefetch still owns that slot: let it finish first
+            self._side.wait_event(self._pf['event'])
+        if self._slot_done[slot] is not None:          # the previous user of this slot's buffers must have finished
+            self._side.wait_event(self._slot_done[slot])
+        try:
+            with torch.cuda.stream(self._side):
+                dev_img = image.to(net.device, non_blocking=True) if not image.is_cuda else image
+                saved_pad = getattr(self, 'pad', None)
+                image4, hw, hw_p = self._pack(dev_img)
+                pad = self.pad
+                if saved_pad is not None:
+                    self.pad = saved_pad
+                outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=False, slot=slot)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+        finally:
+            pass
+        for t in (image4, dev_img):
+            t.record_stream(main)
+        self._pf = dict(ptr=dev_img.data_ptr(), shape=tuple(dev_img.shape), image4=image4, hw=hw, hw_p=hw_p, pad=pad,
+                        outs=outs, event=ev, slot=slot, keep=dev_img)
+        return dev_img
+
     # ---- the per-frame step ----------------------------------------------------------------------
     def step(self, image, mask=None, valid_labels=None, end=False, manually_curated_masks=False,
              disable_memory_updates=False, do_not_add_mask_to_memory=False, return_key_and_stuff=False):
         """inference_core.py:62-152.  image: 3*H*W, mask: num_objects*H*W or None -> prob (K+1)*H*W."""
         self.curr_ti += 1
-        image4, hw, hw_p = self._pack(image)
+        pf, self._pf = self._pf, None
+        if pf is not None and not (image.is_cuda and pf['ptr'] == image.data_ptr() and pf['shape'] == tuple(image.shape)):
+            torch.cuda.current_stream().wait_event(pf['event'])     # stale hint: drop it (after it released its buffers)
+            self._slot_done[pf['slot']] = pf['event']
+            pf = None
+        if pf is not None:
+            image4, hw, hw_p = pf['image4'], pf['hw'], pf['hw_p']
+            self.pad = pf['pad']
+            slot = pf['slot']
+        else:
+            image4, hw, hw_p = self._pack(image)
+            slot = self._slot
+            if self._slot_done[slot] is not None:
+                torch.cuda.current_stream().wait_event(self._slot_done[slot])
         if manually_curated_masks:
             is_mem_frame = (mask is not None) and (not end)
         else:
@@ -97,8 +150,12 @@ class InferenceCore:
         is_normal_update = (not self.deep_update_sync or not is_deep_update) and (not end)
 
         net, mem = self.network, self.memory
-        enc = net.encode_key_nhwc(image4, need_sk=True, need_ek=(self.enable_long_term or need_segment),
-                                  with_skips=need_segment)
+        if pf is not None:
+            torch.cuda.current_stream().wait_event(pf['event'])     # the side stream finished this frame's key encoder
+            enc = pf['outs']
+        else:
+            enc = net.encode_key_nhwc(image4, need_sk=True, need_ek=(self.enable_long_term or need_segment),
+                                      with_skips=need_segment, slot=slot)
         key, shrinkage, selection, f16, f8, f4 = enc[:6]
         skips = enc[6] if len(enc) > 6 else None
         h, w = f16.shape[1], f16.shape[2]
@@ -111,12 +168,12 @@ class InferenceCore:
         if need_segment:
             hidden = mem.get_hidden()
             K = hidden.shape[0]
-            cat16 = net.new_decoder_input(K, h, w, f16.device)
+            cat16 = net.new_decoder_input(K, h, w, f16.device, slot=slot)
             ld = cat16.shape[3]
             mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024,
                                   disable_usage_updates=disable_memory_updates)
             new_hidden, prob, prob_padded = net.segment_nhwc(f16, f8, f4, cat16, hidden, hw, (self.pad[2], self.pad[0]),
-                                                             h_out=is_normal_update, skips=skips)
+                                                             h_out=is_normal_update, skips=skips, slot=slot)
             if is_normal_update:
                 mem.set_hidden(new_hidden)
 
@@ -138,7 +195,7 @@ class InferenceCore:
 
         if is_mem_frame:
             value, hidden = net.encode_value_nhwc(image4, f16, mem.get_hidden(), prob_padded[1:],
-                                                  is_deep_update=is_deep_update)
+                                                  is_deep_update=is_deep_update, slot=slot)
             mem.add_memory(key, shrinkage, value.view(value.shape[0], h * w, value.shape[3]), self.all_labels,
                            selection=selection if self.enable_long_term else None, ignore=is_ignore, hw_shape=(h, w))
             self.last_mem_ti = self.curr_ti
@@ -146,13 +203,27 @@ class InferenceCore:
                 mem.set_hidden(hidden)
                 self.last_deep_update_ti = self.curr_ti
 
+        if image.is_cuda and getattr(net, 'use_graphs', False):
+            done = torch.cuda.Event()
+            done.record()
+            self._slot_done[slot] = done              # the slot's static buffers are free once this point is reached
+            self._slot = slot
         if return_key_and_stuff:
             views = self._key_views(key, shrinkage, selection, h, w)
             return (prob,) + tuple(v.clone() if v is not None else None for v in views)   # caller-owned copies
         return prob
 
+    def _drop_prefetch(self):
+        if self._pf is not None:
+            torch.cuda.current_stream().wait_event(self._pf['event'])
+            self._slot_done[self._pf['slot']] = self._pf['event']
+            self._pf = None
+
     def put_to_permanent_memory(self, image, mask, ti=None):
         """inference_core.py:154-179."""
+        self._drop_prefetch()
+        if self._slot_done[0] is not None:
+            torch.cuda.current_stream().wait_event(self._slot_done[0])
         image4, hw, hw_p = self._pack(image)
         net, mem = self.network, self.memory
         key, shrinkage, selection, f16, _, _ = net.encode_key_nhwc(image4, need_sk=True, need_ek=True)

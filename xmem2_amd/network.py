@@ -272,20 +272,26 @@ class XMem:
         return self._group_res(g, p + '.block2')
 
     # ---- hot path (NHWC) ------------------------------------------------------------------------
-    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True, with_skips=False):
+    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True, with_skips=False, slot=0):
         """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC)
         [+ (skip8, skip4), the decoder's skip convolutions of f8 / f4, when with_skips and the graph path is active].
-        With graphs on, the returned tensors are the stage's static buffers: valid until the next call."""
+        With graphs on, the returned tensors are the stage's static buffers: valid until the next call
+        with the same `slot` (two slots let the key encoder of frame t+1 run while frame t is still being decoded)."""
         self._need_weights()
         overlap = bool(with_skips and self.overlap_skips and self.use_graphs and not ops.eager_only() and image4.shape[0] == 1)
-        out = self._run_stage('key', (need_sk, need_ek, overlap), [image4],
-                              lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap))
+        ops._ws_suffix = f'@key{slot}'      # key-encoder graphs may run on a side stream: never share scratch with the decoder
+        try:
+            out = self._run_stage('key', (need_sk, need_ek, overlap, slot), [image4],
+                                  lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap))
+        finally:
+            ops._ws_suffix = ''
         if with_skips:
             return out if overlap else tuple(out) + (None,)
         return out[:6]
 
     def _encode_key_eager(self, image4, need_sk, need_ek, overlap=False):
         W = self._w
+        self._key_ws = ops._ws_suffix
         x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
         x = ops.maxpool3x3s2(x)
         f4 = self._stage(x, 'key_encoder.res2', 3, self._bottleneck)
@@ -295,17 +301,17 @@ class XMem:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=image4.device)
             self._side.wait_stream(main)                       # fork: f4 is ready
-            ops._ws_suffix = '@side'
+            ops._ws_suffix = '@side4'
             with torch.cuda.stream(self._side):
                 skip4 = ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
-            ops._ws_suffix = ''
+            ops._ws_suffix = self._key_ws
         f8 = self._stage(f4, 'key_encoder.layer2', 4, self._bottleneck)
         if overlap:
             self._side.wait_stream(main)                       # f8 is ready
-            ops._ws_suffix = '@side'
+            ops._ws_suffix = '@side8'
             with torch.cuda.stream(self._side):
                 skip8 = ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
-            ops._ws_suffix = ''
+            ops._ws_suffix = self._key_ws
         f16 = self._stage(f8, 'key_encoder.layer3', 6, self._bottleneck)
         B, h, w, _ = f16.shape
         ld = _pad4(2 * self.key_dim + 1)
@@ -317,10 +323,10 @@ class XMem:
             return key, shr, sel, f16, f8, f4, (skip8, skip4)
         return key, shr, sel, f16, f8, f4
 
-    def encode_value_nhwc(self, image4, f16, hidden, masks, is_deep_update=True):
+    def encode_value_nhwc(self, image4, f16, hidden, masks, is_deep_update=True, slot=0):
         """image4 [1,Hp,Wp,4], f16 [1,h,w,1024], hidden [K,h,w,Ch], masks [K,Hp,Wp] -> value [K,h,w,Cv], hidden."""
         self._need_weights()
-        value, new_hidden = self._run_stage('value', (bool(is_deep_update),), [image4, f16, hidden, masks],
+        value, new_hidden = self._run_stage('value', (bool(is_deep_update), slot), [image4, f16, hidden, masks],
                                             lambda a, b, c, d: self._encode_value_eager(a, b, c, d, is_deep_update),
                                             alias=(1,) if self._is_stage_output(f16) else ())
         if self.use_graphs and new_hidden is not None and new_hidden is not hidden:
@@ -348,27 +354,27 @@ class XMem:
             hidden = ops.gru_gate(values, hidden)
         return value, hidden
 
-    def new_decoder_input(self, K, h, w, device):
+    def new_decoder_input(self, K, h, w, device, slot=0):
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
         Once the decoder stage is captured this is its static input buffer (no copy before the replay)."""
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
         if self.use_graphs and not ops.eager_only():
             for k, st in self._stages.items():
-                if k[0] == 'segment' and tuple(st[1][3].shape) == shape:
+                if k[0] == 'segment' and k[1][-1] == slot and tuple(st[1][3].shape) == shape:
                     return st[1][3]
         return torch.empty(shape, dtype=torch.float32, device=device)
 
-    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True, skips=None):
+    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True, skips=None, slot=0):
         """Decoder + soft aggregation.  cat16 holds the memory readout at channels [1024,1024+Cv).
         Returns new_hidden|None, prob [K+1,H,W] (unpadded), prob_padded [K+1,Hp,Wp]."""
         self._need_weights()
         if skips is not None:
-            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True),
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot),
                                   [f16, f8, f4, cat16, hidden, skips[0], skips[1]],
                                   lambda a, b, c, d, e, s8, s4: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out, (s8, s4)),
                                   alias=(0, 1, 2, 5, 6) if self._is_stage_output(f16) else ())
         else:
-            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), False), [f16, f8, f4, cat16, hidden],
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), False, slot), [f16, f8, f4, cat16, hidden],
                                   lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out),
                                   alias=(0, 1, 2) if self._is_stage_output(f16) else ())
         if self.use_graphs and not ops.eager_only():

@@ -265,9 +265,10 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
                 saver.save(_overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg')
 
     try:
+        next_sample, next_rgb = vid_reader[0], None
         for ti in range(vid_length):
-            sample = vid_reader[ti]
-            rgb = sample.rgb.to(device)
+            sample = next_sample
+            rgb = next_rgb if next_rgb is not None else sample.rgb.to(device)
             msk = labels = None
             if ti in frames_with_masks and sample.mask is not None:
                 msk, labels = mapper.convert_mask(sample.mask, exhaustive=True)
@@ -279,6 +280,9 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             a = perf_counter()
             prob = processor.step(rgb, msk, labels, end=(ti == vid_length - 1),
                                   manually_curated_masks=manually_curated_masks, do_not_add_mask_to_memory=skip_add)
+            if ti + 1 < vid_length:                                  # decode + key-encode the next frame under this one
+                next_sample = vid_reader[ti + 1]
+                next_rgb = processor.prefetch_key(next_sample.rgb.pin_memory())
             done = fetcher.submit((sample, msk is not None), _post_process_gpu(sample, prob))
             total_time += perf_counter() - a
             for tag, out_mask in done:
