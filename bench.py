@@ -199,6 +199,7 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # control plane only (timing barrier + max / sum of two scalars): RCCL by default
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
