@@ -214,6 +214,31 @@ int xmem_weighted_rows(const float* aff, int P, int n, int count, const float* V
  * out_index receives the kept indices in order, *out_count (device int) their number. */
 int xmem_select_greater(const float* usage, int n, const float* threshold_dev, int32_t* out_index, int32_t* out_count, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Annotation-candidate selector (inference/frame_selection/frame_selection.py:99-244).
+ * ------------------------------------------------------------------------------------------ */
+/* Per-frame preparation (frame_selection.py:156-186): nearest-resize the C x H x W mask to h x w (as
+ * torchvision Resize(NEAREST) on a tensor = F.interpolate(mode='nearest')), take the max over its channels,
+ * form the composite key  c = (key * m) * alpha + key * one_minus_alpha  and expand it into the two
+ * K = 2*C_k operands of the similarity: Mexp [HW][2C_k] = [c^2, c], Qexp [HW][2C_k] = [-e, 2 c e],
+ * bsq [HW] = sum_c e c^2 (memory_util.py:20-27).  key / sel are [HW][C_k] rows.  mask may be NULL (c = key).
+ * presence (device int32, nullable) receives #{pixels of the FULL-RES mask with max_c mask > eps}
+ * (frame_selection.py:161-163). */
+int xmem_selector_prepare(const float* key, const float* sel, const float* mask, int C, int H, int W,
+                          int h, int w, int Ck, float alpha, float one_minus_alpha, float eps,
+                          float* Mexp, float* Qexp, float* bsq, int32_t* presence, void* stream);
+
+/* Cycle dissimilarity of every frame f against frame `chosen` (frame_selection.py:218-226):
+ *   out[f] = sum_{i,j} relu( S(mem=c_chosen[i], ms=s_chosen[i]; q=c_f[j], qe=e_f[j])
+ *                          - S(mem=c_f[i],      ms=s_f[i];      q=c_chosen[j], qe=e_chosen[j]) ) / HW^2
+ * Mexp/Qexp [n_frames][HW][2C_k], bsq/shrinkage [n_frames][HW] from xmem_selector_prepare; valid [n_frames]
+ * uint8 (nullable; 0 => out[f] = 0 without computing, frame_selection.py:201-203).  out [n_frames] double
+ * (deterministic fixed-order reduction).  C_k = 64. */
+size_t xmem_cycle_dissimilarity_workspace_bytes(int n_frames, int HW);
+int xmem_cycle_dissimilarity(const float* Mexp, const float* Qexp, const float* bsq, const float* shrinkage,
+                             int n_frames, int HW, int Ck, int chosen, const uint8_t* valid, double* out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -851,3 +851,69 @@ class RefMaskMapper:
         for l, i in self.remappings.items():
             out[mask == i] = l
         return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Annotation-candidate selector
+# ---------------------------------------------------------------------------------------------
+# NOTE parity: inference/frame_selection/* cannot be imported in the build container (torchvision / cv2 are absent), so
+# this restatement is NOT pinned against a run of the reference.  Its arithmetic core is `get_similarity` above (pinned
+# bit-equal); the loop below follows frame_selection.py:99-244 line by line, with torchvision's tensor
+# Resize(NEAREST) restated as F.interpolate(mode='nearest'), which is what torchvision dispatches to for tensors.
+
+def cycle_dissimilarity(key_a, shr_a, sel_a, key_b, shr_b, sel_b):
+    """frame_selection.py:218-226.  key_* C_k x h x w (composite), shr_* 1 x h x w, sel_* C_k x h x w -> 0-d tensor."""
+    fwd = get_similarity(key_a.unsqueeze(0), shr_a.unsqueeze(0), key_b.unsqueeze(0), sel_b.unsqueeze(0))
+    rev = get_similarity(key_b.unsqueeze(0), shr_b.unsqueeze(0), key_a.unsqueeze(0), sel_a.unsqueeze(0))
+    diff = (fwd - rev).to(torch.float32)
+    return F.relu(diff).sum() / diff.numel()
+
+
+def composite_keys_and_validity(keys, masks, previously_chosen, alpha, min_mask_presence_percent, epsilon):
+    """frame_selection.py:150-186: mask presence test + mask-weighted composite keys (None for ignored frames)."""
+    n = len(keys)
+    h, w = keys[0].shape[1:3]
+    valid = np.full(n, True)
+    composite = []
+    for i, mask in enumerate(masks):
+        m3 = mask if mask.ndim == 3 else mask.unsqueeze(0)
+        merged = m3.max(dim=0).values
+        percent = (merged > epsilon).sum() / merged.numel() * 100
+        if percent < min_mask_presence_percent and i not in previously_chosen:
+            valid[i] = False
+            composite.append(None)
+            continue
+        small = F.interpolate(m3.unsqueeze(0).float(), size=(h, w), mode='nearest')[0]
+        ck = keys[i] * small.max(dim=0, keepdim=True).values
+        ck = ck * alpha + keys[i] * (1 - alpha)
+        composite.append(ck.to(dtype=keys[i].dtype))
+    return composite, valid
+
+
+def select_next_candidates(keys, shrinkages, selections, masks, num_next_candidates, previously_chosen_candidates=(0,),
+                           alpha=0.5, min_mask_presence_percent=0.25, only_new_candidates=True, epsilon=0.5):
+    """frame_selection.py:99-244 (greedy farthest-point selection under the cycle dissimilarity), O(k^2 N) like the
+    reference.  keys F x C_k x h x w, shrinkages F x 1 x h x w, selections F x C_k x h x w, masks list of C x H x W."""
+    assert len(keys) == len(masks) and len(keys) > 0
+    assert num_next_candidates > 0 and len(previously_chosen_candidates) > 0
+    assert 0.0 <= alpha <= 1.0 and min_mask_presence_percent >= 0
+    assert len(previously_chosen_candidates) < len(keys)
+    n = len(keys)
+    composite, valid = composite_keys_and_validity(keys, masks, previously_chosen_candidates, alpha,
+                                                   min_mask_presence_percent, epsilon)
+    chosen = list(previously_chosen_candidates)
+    trace = []
+    for _ in range(num_next_candidates):
+        scores = []
+        for j in range(n):
+            if not valid[j]:
+                scores.append(0)
+                continue
+            per_chosen = [cycle_dissimilarity(composite[m], shrinkages[m], selections[m],
+                                              composite[j], shrinkages[j], selections[j]) for m in chosen]
+            scores.append(min(per_chosen))
+        scores_t = torch.tensor(scores)
+        trace.append(scores_t.to(torch.float32).numpy().copy())
+        chosen.append(int(torch.argmax(scores_t)))
+    select_next_candidates.last_scores = trace
+    return chosen[len(previously_chosen_candidates):] if only_new_candidates else chosen

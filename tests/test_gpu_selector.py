@@ -1,0 +1,154 @@
+"""Annotation-candidate selector: HIP path through the C ABI vs the oracle restatement of
+inference/frame_selection/frame_selection.py:99-244.  Scores are fp32 sums of ~HW^2 positive terms: the HIP kernel
+reduces in a different order (and in fp64 across blocks), so scores are compared at rtol 2e-4 and the greedy
+choice must be identical whenever the oracle's best score leads the runner-up by more than that tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(F, h, w, H, W, seed, n_obj=2, empty=()):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(3, 64, h, w, generator=g) * 0.5                      # three scene clusters
+    scale = 0.05 + 0.4 * torch.rand(F, generator=g)
+    keys = base[torch.arange(F) % 3] + torch.randn(F, 64, h, w, generator=g) * scale.view(F, 1, 1, 1)
+    shr = 1 + torch.rand(F, 1, h, w, generator=g) ** 2 * 3
+    sel = torch.rand(F, 64, h, w, generator=g)
+    masks = []
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    for f in range(F):
+        m = torch.zeros(n_obj, H, W)
+        if f not in empty:
+            for o in range(n_obj):
+                cy, cx = H * (0.3 + 0.4 * o) + 2 * f, W * (0.3 + 0.3 * o) + 3 * f
+                m[o] = (((yy - cy) / (H * 0.18)) ** 2 + ((xx - cx) / (W * 0.15)) ** 2 < 1).float() * (0.6 + 0.4 * torch.rand(H, W, generator=g))
+        masks.append(m)
+    return keys, shr, sel, masks
+
+
+def _compare(keys, shr, sel, masks, k, prev, alpha, pct=0.25, eps=0.5):
+    from oracle import cpu_ref
+    from xmem2_amd.frame_selection import select_next_candidates
+    want = cpu_ref.select_next_candidates(keys, shr, sel, masks, k, previously_chosen_candidates=prev, alpha=alpha,
+                                          min_mask_presence_percent=pct, epsilon=eps)
+    want_trace = cpu_ref.select_next_candidates.last_scores
+    got = select_next_candidates(keys, shr, sel, masks, k, previously_chosen_candidates=prev, alpha=alpha,
+                                 min_mask_presence_percent=pct, epsilon=eps, device='cuda:0')
+    got_trace = select_next_candidates.last_scores
+    decisive = True
+    for it, (a, b) in enumerate(zip(got_trace, want_trace)):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-7, err_msg=f'scores of iteration {it}')
+        top = np.sort(b)[::-1]
+        if len(top) > 1 and top[0] - top[1] <= 4e-4 * abs(top[0]):
+            decisive = False
+        if not decisive:
+            break
+    if decisive:
+        assert got == want
+    return got, want
+
+
+@pytest.mark.parametrize('alpha', [0.0, 0.5, 1.0, 0.3])
+def test_selector_small_matches_oracle(alpha):
+    keys, shr, sel, masks = _inputs(7, 6, 8, 96, 128, seed=3)
+    got, want = _compare(keys, shr, sel, masks, k=3, prev=(0,), alpha=alpha)
+    assert len(got) == 3
+
+
+def test_selector_ragged_tile_and_several_previous():
+    keys, shr, sel, masks = _inputs(6, 11, 13, 170, 200, seed=5, n_obj=1)      # HW = 143: one full + one ragged tile
+    _compare(keys, shr, sel, masks, k=2, prev=(0, 4), alpha=0.5)
+
+
+def test_selector_ignores_frames_with_tiny_masks():
+    keys, shr, sel, masks = _inputs(8, 6, 8, 96, 128, seed=7, empty=(2, 5, 0))
+    got, want = _compare(keys, shr, sel, masks, k=3, prev=(0,), alpha=0.5)      # frame 0 is previous: kept although empty
+    assert 2 not in got and 5 not in got
+
+
+def test_selector_all_invalid_picks_frame_zero():
+    keys, shr, sel, masks = _inputs(5, 6, 8, 96, 128, seed=9, empty=tuple(range(5)))
+    got, want = _compare(keys, shr, sel, masks, k=1, prev=(1,), alpha=0.5)
+    assert got == want == [0]
+    # a second pick makes the reference dereference the None composite key of the ignored frame it just chose
+    # (frame_selection.py:212-214, AttributeError); this path keeps going and repeats frame 0
+    from xmem2_amd.frame_selection import select_next_candidates
+    assert select_next_candidates(keys, shr, sel, masks, 2, previously_chosen_candidates=(1,)) == [0, 0]
+
+
+def test_selector_480p_shape():
+    keys, shr, sel, masks = _inputs(5, 30, 54, 480, 864, seed=11, n_obj=1)
+    _compare(keys, shr, sel, masks, k=2, prev=(0,), alpha=0.5)
+
+
+def test_selector_only_new_candidates_false_and_asserts():
+    from xmem2_amd.frame_selection import select_next_candidates
+    keys, shr, sel, masks = _inputs(4, 6, 8, 96, 128, seed=13)
+    out = select_next_candidates(keys, shr, sel, masks, 1, previously_chosen_candidates=[0, 2], only_new_candidates=False)
+    assert out[:2] == [0, 2] and len(out) == 3
+    with pytest.raises(AssertionError):
+        select_next_candidates(keys, shr, sel, masks[:-1], 1)
+    with pytest.raises(AssertionError):
+        select_next_candidates(keys, shr, sel, masks, 1, alpha=1.5)
+    with pytest.raises(AssertionError):
+        select_next_candidates(keys, shr, sel, masks, 1, previously_chosen_candidates=[0, 1, 2, 3])
+
+
+def test_extract_keys_and_selection_on_network_keys(hip_net):
+    """extract_keys -> select_next_candidates on keys produced by the HIP key encoder; the oracle scores the same keys."""
+    from conftest import base_config
+    from oracle import cpu_ref
+    from xmem2_amd import InferenceCore
+    from xmem2_amd.frame_selection import extract_keys, select_next_candidates
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    T, H, W = 6, 96, 128
+    frames = synthetic_frames(T, H, W, seed=21)
+    masks = [torch.from_numpy(m) for m in synthetic_masks(T, 2, H, W)]
+    core = InferenceCore(hip_net, config=base_config())
+    fk, fs, fe, device, n, key_sum = extract_keys([torch.from_numpy(f) for f in frames], core, flatten=False)
+    assert n == T and fk[0].shape == (1, 64, H // 16, W // 16) and not fk[0].is_cuda
+    np.testing.assert_allclose(key_sum.cpu().numpy(), sum(k.double() for k in fk).numpy(), rtol=1e-12)
+    keys, shr, sel = torch.cat(fk), torch.cat(fs), torch.cat(fe)
+    got = select_next_candidates(keys, shr, sel, masks, 2, previously_chosen_candidates=[0], device='cuda:0')
+    got_trace = select_next_candidates.last_scores
+    want = cpu_ref.select_next_candidates(keys, shr, sel, masks, 2, previously_chosen_candidates=[0])
+    for a, b in zip(got_trace, cpu_ref.select_next_candidates.last_scores):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-7)
+    assert got == want
+    flat = extract_keys([torch.from_numpy(frames[0])], core, flatten=True)
+    assert flat[0][0].shape == (1, 64, (H // 16) * (W // 16))
+
+
+def test_select_k_next_best_annotation_candidates_on_files(tmp_path):
+    """run_on_video.py:285-370 end to end on files: inference writes the masks, the selector reads them back."""
+    from PIL import Image
+    from xmem2_amd.run_on_video import select_k_next_best_annotation_candidates, _pil_to_tensor01
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    imgs, msks, out = tmp_path / 'JPEGImages', tmp_path / 'Annotations', tmp_path / 'out'
+    imgs.mkdir(); msks.mkdir()
+    t, hw = 6, (96, 128)
+    frames = synthetic_frames(t, *hw); masks = synthetic_masks(t, 1, *hw)
+    palette = [0, 0, 0, 255, 255, 255] + [0] * (256 * 3 - 6)
+    for i in range(t):
+        rgb = np.clip((frames[i].transpose(1, 2, 0) * 0.229 + 0.45) * 255, 0, 255).astype(np.uint8)
+        Image.fromarray(rgb).save(imgs / f'frame_{i:06d}.png')
+        im = Image.fromarray(masks[i, 0].astype(np.uint8), mode='P'); im.putpalette(palette); im.save(msks / f'frame_{i:06d}.png')
+    cfg = {'model': None, 'size': -1, 'mem_every': 2}
+    picked = select_k_next_best_annotation_candidates(str(imgs), str(msks), str(out), k=2, print_progress=False,
+                                                      previously_chosen_candidates=[0], use_previously_predicted_masks=False,
+                                                      overwrite_config=dict(cfg), save_overlay=False)
+    assert len(picked) == 2 and all(0 <= p < t for p in picked)
+    # second call re-uses the written masks and must agree
+    again = select_k_next_best_annotation_candidates(str(imgs), str(msks), str(out), k=2, print_progress=False,
+                                                     previously_chosen_candidates=[0], use_previously_predicted_masks=True,
+                                                     overwrite_config=dict(cfg))
+    assert again == picked
+    m = _pil_to_tensor01(Image.open(sorted((out / 'masks').iterdir())[0]))
+    assert m.dim() == 3 and float(m.max()) <= 1.0
+    with pytest.raises(FileNotFoundError):
+        os_masks = sorted((out / 'masks').iterdir())
+        os_masks[-1].unlink()
+        select_k_next_best_annotation_candidates(str(imgs), str(msks), str(out), k=1, print_progress=False,
+                                                 use_previously_predicted_masks=True, overwrite_config=dict(cfg))

@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'consolidate.hip']
+SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'consolidate.hip', 'selector.hip']
 LIB = os.path.join(CSRC, 'libxmem_hip.so')
 ARCH = 'gfx950'
 

@@ -418,6 +418,35 @@ def similarity_dense(key, shrinkage, qk, qe):
     return out
 
 
+def selector_prepare(key_rows, sel_rows, mask, h, w, alpha, eps, Mexp, Qexp, bsq, presence):
+    """One frame of the candidate selector (frame_selection.py:156-186): key_rows/sel_rows [HW,Ck], mask [C,H,W] | None,
+    outputs are views into the per-video operand arrays (Mexp/Qexp [HW,2Ck], bsq [HW], presence int32[1])."""
+    hw, ck = key_rows.shape
+    if hw != h * w:
+        raise ValueError('key rows do not match h*w')
+    if mask is not None:
+        Cm, H, W = mask.shape
+        mask = _req(mask, 'mask')
+    else:
+        Cm = H = W = 0
+    check(load().xmem_selector_prepare(ptr(_req(key_rows, 'key')), ptr(_req(sel_rows, 'selection')), ptr(mask), Cm, H, W,
+                                       h, w, ck, float(alpha), float(1 - alpha), float(eps),
+                                       ptr(Mexp), ptr(Qexp), ptr(bsq), ptr(presence), stream_ptr()))
+
+
+def cycle_dissimilarity(Mexp, Qexp, bsq, shrinkage, chosen, valid=None):
+    """Score every frame against frame `chosen` (frame_selection.py:218-226).  Mexp/Qexp [F,HW,2Ck]; bsq/shrinkage [F,HW];
+    valid uint8 [F] | None.  Returns float64 [F]."""
+    F, HW, k2 = Mexp.shape
+    out = torch.empty((F,), dtype=torch.float64, device=Mexp.device)
+    nbytes = load().xmem_cycle_dissimilarity_workspace_bytes(F, HW)
+    ws = workspace(nbytes, Mexp.device, 'selector')
+    check(load().xmem_cycle_dissimilarity(ptr(_req(Mexp, 'Mexp')), ptr(_req(Qexp, 'Qexp')), ptr(_req(bsq, 'bsq')),
+                                          ptr(_req(shrinkage, 'shrinkage')), F, HW, k2 // 2, int(chosen), ptr(valid),
+                                          ptr(out), ptr(ws), nbytes, stream_ptr()))
+    return out
+
+
 def usage_ratio(use, life):
     out = torch.empty_like(use)
     check(load().xmem_usage_ratio(ptr(use), ptr(life), ptr(out), use.numel(), stream_ptr()))

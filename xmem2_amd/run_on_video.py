@@ -310,3 +310,64 @@ def run_on_video(imgs_in_path, masks_in_path, masks_out_path, frames_with_masks:
     return _inference_on_video(imgs_in_path=imgs_in_path, masks_in_path=masks_in_path, masks_out_path=masks_out_path,
                                frames_with_masks=frames_with_masks, compute_iou=compute_iou,
                                print_progress=print_progress, **kwargs)
+
+
+def _pil_to_tensor01(pic):
+    """What torchvision's ToTensor yields for the PNG modes the harness writes/reads (run_on_video.py:334,362):
+    uint8 planes scaled by 1/255, C x H x W; palette images contribute their raw INDEX plane (so object id 1 becomes
+    1/255 - the reference feeds exactly that to the selector)."""
+    arr = np.array(pic, copy=True)
+    if pic.mode == '1':
+        arr = arr.astype(np.uint8) * 255
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+    return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t.to(torch.float32)
+
+
+def select_k_next_best_annotation_candidates(imgs_in_path, masks_in_path, masks_out_path=None, k: int = 5,
+                                             print_progress=True, previously_chosen_candidates=[0],
+                                             use_previously_predicted_masks=True, alpha=0.5,
+                                             min_mask_presence_percent=0.25, **kwargs):
+    """inference/run_on_video.py:285-370, same arguments and return (list of new frame indices)."""
+    import tempfile
+    from pathlib import Path
+    from PIL import Image
+    from .frame_selection import extract_keys, select_next_candidates
+
+    if not torch.cuda.is_available():
+        raise RuntimeError('xmem2_amd needs an MI355X (HIP) device - there is no CPU path')
+    device = torch.device('cuda', torch.cuda.current_device())
+    config = dict(VIDEO_INFERENCE_CONFIG)
+    config.update(kwargs.get('overwrite_config') or {})     # the reference extracts keys with the default config
+    _, processor, vid_reader = _load_main_objects(imgs_in_path, masks_in_path, config, device)
+    frame_keys, shrinkages, selections, *_ = extract_keys(vid_reader, processor, print_progress=print_progress,
+                                                          flatten=False, keep_on_device=True)
+    tmp = None
+    p_masks_out = Path(masks_out_path) if masks_out_path is not None else None
+    if use_previously_predicted_masks:
+        assert masks_out_path is not None, \
+            'When `use_existing_masks=True`, you need to put the path to previously predicted masks in `masks_out_path`'
+    else:
+        if p_masks_out is None:
+            tmp = tempfile.TemporaryDirectory()
+            p_masks_out = Path(tmp.name)
+        run_on_video(imgs_in_path=imgs_in_path, masks_in_path=masks_in_path, masks_out_path=p_masks_out,
+                     frames_with_masks=previously_chosen_candidates, compute_iou=False, print_progress=print_progress,
+                     **kwargs)
+    try:
+        masks = [_pil_to_tensor01(Image.open(p)) for p in sorted((p_masks_out / 'masks').iterdir())]
+    except Exception:
+        warn('Loading previously predicting masks failed for `select_k_next_best_annotation_candidates`.')
+        raise
+    if len(masks) != len(frame_keys):
+        raise FileNotFoundError(f'Not enough masks ({len(masks)}) for {len(frame_keys)} frames provided when using '
+                                f'`use_previously_predicted_masks=True`!')
+    chosen = select_next_candidates(torch.cat(frame_keys), shrinkages=torch.cat(shrinkages), selections=torch.cat(selections),
+                                    masks=masks, num_next_candidates=k,
+                                    previously_chosen_candidates=previously_chosen_candidates, print_progress=print_progress,
+                                    alpha=alpha, only_new_candidates=True,
+                                    min_mask_presence_percent=min_mask_presence_percent, device=device)
+    if tmp is not None:
+        tmp.cleanup()
+    return chosen
