@@ -192,3 +192,44 @@ def test_update_schedules_vs_oracle(hip_net, ref_net, cfg_over, curated):
         assert float(hd.max()) < 5e-3, f'hidden state diverged at frame {ti}: {float(hd.max()):.2e}'
     with pytest.raises(AssertionError):
         core.update_config(dict(cfg, enable_long_term=False))
+
+
+def test_prefetch_keys_is_only_a_hint(hip_net):
+    """Batched key-encoder hints (prefetch_keys) must not change what step() computes: a hinted stream (batches of 4,
+    a batch of 3, single hints, a stale hint that gets dropped, memory frames + a consolidation, 2 objects) against an
+    un-hinted stream on the same frames.  Batched convolutions may pick other tile plans, so equality is to fp32
+    round-off, not bitwise."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    t, hw = 20, (96, 128)
+    fr = T(synthetic_frames(t, *hw)).cuda(); mk = T(synthetic_masks(t, 2, *hw)).cuda()
+    cfg = base_config(mem_every=2, max_mid_term_frames=4, min_mid_term_frames=2, num_prototypes=16)
+    cores = [InferenceCore(hip_net, dict(cfg)) for _ in range(2)]
+    for c in cores:
+        c.set_all_labels([1, 2])
+        c.put_to_permanent_memory(fr[0], mk[0])
+    plain = [cores[0].step(fr[i], None, None).clone() for i in range(1, t)]
+    c = cores[1]
+    hinted = []
+    schedule = {1: 4, 5: 4, 9: 3, 12: 1, 13: 1, 14: 4}               # frame index -> hint size issued before it
+    i = 1
+    while i < t:
+        if i in schedule:
+            devs = c.prefetch_keys([fr[j] for j in range(i, min(i + schedule[i], t))])
+            assert all(d.data_ptr() == fr[i + k].data_ptr() for k, d in enumerate(devs))
+        if i == 16:                                                  # hinted frames 14..17 pending: jump the queue
+            c.prefetch_keys([fr[18], fr[19]])                         # more hints on top, then an out-of-order frame
+            hinted.append(c.step(fr[16].clone(), None, None).clone())
+            assert len(c._pfq) == 0                                  # stale hints were dropped
+        else:
+            hinted.append(c.step(fr[i], None, None).clone())
+        i += 1
+    assert cores[0].memory.long_mem.size == c.memory.long_mem.size > 0
+    assert cores[0].memory.temporary_work_mem.size == c.memory.temporary_work_mem.size
+    for a, b in zip(plain, hinted):
+        assert float((a - b).abs().max()) < 2e-3
+        assert float((ops.argmax_u8(a) != ops.argmax_u8(b)).float().mean()) < 1e-4
+    with pytest.raises(ValueError):
+        c.prefetch_keys([fr[0], fr[1][:, :64]])

@@ -4,6 +4,8 @@ driving the HIP kernels.  ``step()``, ``put_to_permanent_memory()``, ``clear_mem
 ``permanent_memory_frames`` keep the reference's signatures and semantics; tensors enter and leave in the
 reference's conventions (image ``3 x H x W`` float32 normalised, mask ``K x H x W``, prob ``(K+1) x H x W``).
 """
+import collections
+
 import torch
 
 from . import ops
@@ -21,9 +23,9 @@ class InferenceCore:
         # frame pipelining: prefetch_key() runs the key encoder of the NEXT frame on a side stream (own graph slot and
         # scratch) while the current frame's readout / decoder occupy the main stream
         self._side = None
-        self._pf = None
-        self._slot = 0
-        self._slot_done = {0: None, 1: None}
+        self._pfq = collections.deque()      # prefetched frames in the order step() will consume them
+        self._group_free = {}                # buffer group -> event after which the side stream may overwrite it
+        self._group_parity = {}
         # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
         if getattr(network, 'device', None) is not None and network.device.type == 'cuda':
             with torch.cuda.device(network.device):
@@ -86,58 +88,82 @@ class InferenceCore:
         return tuple(v.clone() for v in self._key_views(key, shr, sel, f16.shape[1], f16.shape[2]))
 
     def prefetch_key(self, image):
-        """Enqueue the key encoder for a FUTURE frame.  `image` (3 x H x W float32, CPU-pinned or device tensor that is
-        already complete) is returned as the device tensor to hand to the next `step()`; the call is a no-op hint
-        when graphs are off.  Not part of the reference surface: `step()` behaves identically without it."""
+        """Enqueue the key encoder for the NEXT frame (see `prefetch_keys`); returns the device tensor to hand to
+        the next `step()`."""
+        return self.prefetch_keys([image])[0]
+
+    def prefetch_keys(self, images):
+        """Enqueue ONE batched key-encoder pass for the next `len(images)` frames on a side stream.
+
+        The key encoder depends on nothing but the image, so a streaming caller that already holds the coming frames
+        (the reference's DataLoader does, inference/run_on_video.py:80-92) can hint them: the pass runs in its own HIP
+        graph and scratch while the current frames are still being read out / decoded on the main stream, and a batch
+        of frames amortises the launch-bound 1/16-resolution layers (1.16 -> 0.82 ms per frame at batch 4).  `images`:
+        3 x H x W float32 tensors of one shape (pinned-CPU, or device tensors that are already complete).  Returns the
+        device tensors to pass to the following `step()` calls IN ORDER; a `step()` on any other tensor simply drops
+        the pending hints.  Not part of the reference surface: `step()` computes the same function without it."""
         net = self.network
+        images = list(images)
+        if not images:
+            return []
         if not (getattr(net, 'use_graphs', False) and net.device.type == 'cuda') or ops.eager_only():
-            return image.to(net.device) if not image.is_cuda else image
+            return [im.to(net.device) if not im.is_cuda else im for im in images]
+        if any(tuple(im.shape) != tuple(images[0].shape) for im in images):
+            raise ValueError('prefetch_keys: all frames of a batch must have the same shape')
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=net.device)
-        slot = self._slot ^ 1
-        if self._pf is not None:                       # an unused prefetch still owns that slot: let it finish first
-            self._side.wait_event(self._pf['event'])
-        if self._slot_done[slot] is not None:          # the previous user of this slot's buffers must have finished
-            self._side.wait_event(self._slot_done[slot])
-        try:
-            with torch.cuda.stream(self._side):
-                dev_img = image.to(net.device, non_blocking=True) if not image.is_cuda else image
-                saved_pad = getattr(self, 'pad', None)
-                image4, hw, hw_p = self._pack(dev_img)
-                pad = self.pad
-                if saved_pad is not None:
-                    self.pad = saved_pad
-                outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=False, slot=slot)
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-        finally:
-            pass
-        for t in (image4, dev_img):
+        B = len(images)
+        par = self._group_parity.get(B, 1) ^ 1                   # two buffer groups per batch size, used alternately
+        gid = ('g', B, par)
+        if any(e['gid'] == gid for e in self._pfq):              # unconsumed frames still live there: give them up
+            self._drop_prefetch()
+        self._group_parity[B] = par
+        if self._group_free.get(gid) is not None:                # main-stream readers of the group's buffers are done
+            self._side.wait_event(self._group_free[gid])
+        saved_pad = getattr(self, 'pad', None)
+        with torch.cuda.stream(self._side):
+            devs = [im.to(net.device, non_blocking=True) if not im.is_cuda else im for im in images]
+            packed = [self._pack(d) for d in devs]
+            pad = self.pad
+            image4 = packed[0][0] if B == 1 else torch.cat([q[0] for q in packed], 0)
+            outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=True, slot=gid, inline_skips=True)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        if saved_pad is not None:
+            self.pad = saved_pad
+        for t in [image4] + devs:
             t.record_stream(main)
-        self._pf = dict(ptr=dev_img.data_ptr(), shape=tuple(dev_img.shape), image4=image4, hw=hw, hw_p=hw_p, pad=pad,
-                        outs=outs, event=ev, slot=slot, keep=dev_img)
-        return dev_img
+        key, shr, sel, f16, f8, f4 = outs[:6]
+        skip8, skip4 = outs[6]
+        n = f16.shape[1] * f16.shape[2]
+        _, hw, hw_p = packed[0]
+        for i, d in enumerate(devs):
+            self._pfq.append(dict(ptr=d.data_ptr(), shape=tuple(d.shape), image4=image4[i:i + 1], hw=hw, hw_p=hw_p, pad=pad,
+                                  outs=(key[i * n:(i + 1) * n], shr[i * n:(i + 1) * n], sel[i * n:(i + 1) * n],
+                                        f16[i:i + 1], f8[i:i + 1], f4[i:i + 1], (skip8[i:i + 1], skip4[i:i + 1])),
+                                  event=ev, slot=(gid, i), gid=gid, keep=d))
+        return devs
 
     # ---- the per-frame step ----------------------------------------------------------------------
     def step(self, image, mask=None, valid_labels=None, end=False, manually_curated_masks=False,
              disable_memory_updates=False, do_not_add_mask_to_memory=False, return_key_and_stuff=False):
         """inference_core.py:62-152.  image: 3*H*W, mask: num_objects*H*W or None -> prob (K+1)*H*W."""
         self.curr_ti += 1
-        pf, self._pf = self._pf, None
-        if pf is not None and not (image.is_cuda and pf['ptr'] == image.data_ptr() and pf['shape'] == tuple(image.shape)):
-            torch.cuda.current_stream().wait_event(pf['event'])     # stale hint: drop it (after it released its buffers)
-            self._slot_done[pf['slot']] = pf['event']
-            pf = None
+        pf = None
+        if self._pfq:
+            head = self._pfq[0]
+            if image.is_cuda and head['ptr'] == image.data_ptr() and head['shape'] == tuple(image.shape):
+                pf = self._pfq.popleft()
+            else:
+                self._drop_prefetch()                               # stale hints: give them up
         if pf is not None:
             image4, hw, hw_p = pf['image4'], pf['hw'], pf['hw_p']
             self.pad = pf['pad']
             slot = pf['slot']
         else:
             image4, hw, hw_p = self._pack(image)
-            slot = self._slot
-            if self._slot_done[slot] is not None:
-                torch.cuda.current_stream().wait_event(self._slot_done[slot])
+            slot = 0                                                # main-stream buffers: stream order protects them
         if manually_curated_masks:
             is_mem_frame = (mask is not None) and (not end)
         else:
@@ -203,27 +229,27 @@ class InferenceCore:
                 mem.set_hidden(hidden)
                 self.last_deep_update_ti = self.curr_ti
 
-        if image.is_cuda and getattr(net, 'use_graphs', False):
+        if pf is not None:
             done = torch.cuda.Event()
             done.record()
-            self._slot_done[slot] = done              # the slot's static buffers are free once this point is reached
-            self._slot = slot
+            self._group_free[pf['gid']] = done        # latest main-stream reader of that group's key-encoder buffers
         if return_key_and_stuff:
             views = self._key_views(key, shrinkage, selection, h, w)
             return (prob,) + tuple(v.clone() if v is not None else None for v in views)   # caller-owned copies
         return prob
 
+    def cancel_prefetch(self):
+        """Forget pending `prefetch_keys` hints (the next `step()` runs its own key encoder)."""
+        self._drop_prefetch()
+
     def _drop_prefetch(self):
-        if self._pf is not None:
-            torch.cuda.current_stream().wait_event(self._pf['event'])
-            self._slot_done[self._pf['slot']] = self._pf['event']
-            self._pf = None
+        while self._pfq:
+            e = self._pfq.popleft()
+            torch.cuda.current_stream().wait_event(e['event'])
 
     def put_to_permanent_memory(self, image, mask, ti=None):
         """inference_core.py:154-179."""
         self._drop_prefetch()
-        if self._slot_done[0] is not None:
-            torch.cuda.current_stream().wait_event(self._slot_done[0])
         image4, hw, hw_p = self._pack(image)
         net, mem = self.network, self.memory
         key, shrinkage, selection, f16, _, _ = net.encode_key_nhwc(image4, need_sk=True, need_ek=True)

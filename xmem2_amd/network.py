@@ -236,8 +236,16 @@ class XMem:
         return static_out
 
     def _is_stage_output(self, t):
-        return any(any(isinstance(o, torch.Tensor) and o.data_ptr() == t.data_ptr() for o in st[2])
-                   for k, st in self._stages.items() if k[0] == 'key')
+        """True when `t` lives inside a static output buffer of a key-encoder stage (a whole output, or the slice of one
+        frame of a batched pass): such tensors keep their address, so later stages may capture them in place."""
+        a = t.data_ptr()
+        for k, st in self._stages.items():
+            if k[0] != 'key':
+                continue
+            for o in st[2]:
+                if isinstance(o, torch.Tensor) and o.data_ptr() <= a < o.data_ptr() + o.numel() * o.element_size():
+                    return True
+        return False
 
     # ---- building blocks (NHWC) -----------------------------------------------------------------
     def _bottleneck(self, x, p):
@@ -272,24 +280,26 @@ class XMem:
         return self._group_res(g, p + '.block2')
 
     # ---- hot path (NHWC) ------------------------------------------------------------------------
-    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True, with_skips=False, slot=0):
+    def encode_key_nhwc(self, image4, need_sk=True, need_ek=True, with_skips=False, slot=0, inline_skips=False):
         """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC)
         [+ (skip8, skip4), the decoder's skip convolutions of f8 / f4, when with_skips and the graph path is active].
         With graphs on, the returned tensors are the stage's static buffers: valid until the next call
         with the same `slot` (two slots let the key encoder of frame t+1 run while frame t is still being decoded)."""
         self._need_weights()
-        overlap = bool(with_skips and self.overlap_skips and self.use_graphs and not ops.eager_only() and image4.shape[0] == 1)
+        overlap = bool(with_skips and not inline_skips and self.overlap_skips and self.use_graphs and not ops.eager_only()
+                       and image4.shape[0] == 1)
+        inline = bool(with_skips and inline_skips)      # a prefetched pass also runs the decoder's skip convolutions
         ops._ws_suffix = f'@key{slot}'      # key-encoder graphs may run on a side stream: never share scratch with the decoder
         try:
-            out = self._run_stage('key', (need_sk, need_ek, overlap, slot), [image4],
-                                  lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap))
+            out = self._run_stage('key', (need_sk, need_ek, overlap, inline, slot), [image4],
+                                  lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap, inline))
         finally:
             ops._ws_suffix = ''
         if with_skips:
-            return out if overlap else tuple(out) + (None,)
+            return out if (overlap or inline) else tuple(out) + (None,)
         return out[:6]
 
-    def _encode_key_eager(self, image4, need_sk, need_ek, overlap=False):
+    def _encode_key_eager(self, image4, need_sk, need_ek, overlap=False, inline_skips=False):
         W = self._w
         self._key_ws = ops._ws_suffix
         x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
@@ -318,6 +328,9 @@ class XMem:
         proj = torch.empty((B, h, w, ld), dtype=torch.float32, device=f16.device)
         ops.conv2d(f16, W['key_proj'], out=proj, out_ld=ld)
         key, shr, sel = ops.key_post(proj, self.key_dim, need_sk, need_ek)
+        if inline_skips:                      # same stream: f8 / f4 only depend on the image (model/modules.py:186,231-232)
+            return key, shr, sel, f16, f8, f4, (ops.conv2d(f8, W['decoder.up_16_8.skip_conv']),
+                                                ops.conv2d(f4, W['decoder.up_8_4.skip_conv']))
         if overlap:
             main.wait_stream(self._side)                       # join before the stage (and its graph capture) ends
             return key, shr, sel, f16, f8, f4, (skip8, skip4)

@@ -12,6 +12,7 @@ What is reproduced from the reference: config merge and the derived ``enable_lon
 (:115-123) and the output layout ``<out>/masks/<frame>.png`` (+ ``overlay/<frame>.jpg``).
 Not reproduced: mp4 extraction (needs cv2), deterministic augmentations.
 """
+import collections
 import os
 import queue
 import threading
@@ -264,11 +265,25 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             if save_overlay:
                 saver.save(_overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg')
 
+    key_batch = max(1, int(config.get('key_batch', 4)))                # frames per batched key-encoder hint
+    pending, next_idx = collections.deque(), 0                       # decoded + hinted frames, in frame order
+
+    def refill():
+        nonlocal next_idx
+        remaining = vid_length - next_idx
+        if remaining <= 0:
+            return
+        n = key_batch if remaining >= key_batch else 1               # the tail goes frame by frame (no new graph shapes)
+        samples = [vid_reader[next_idx + j] for j in range(n)]
+        devs = processor.prefetch_keys([smp.rgb.pin_memory() for smp in samples])
+        pending.extend(zip(samples, devs))
+        next_idx += n
+
     try:
-        next_sample, next_rgb = vid_reader[0], None
         for ti in range(vid_length):
-            sample = next_sample
-            rgb = next_rgb if next_rgb is not None else sample.rgb.to(device)
+            if not pending:
+                refill()
+            sample, rgb = pending.popleft()
             msk = labels = None
             if ti in frames_with_masks and sample.mask is not None:
                 msk, labels = mapper.convert_mask(sample.mask, exhaustive=True)
@@ -280,9 +295,8 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             a = perf_counter()
             prob = processor.step(rgb, msk, labels, end=(ti == vid_length - 1),
                                   manually_curated_masks=manually_curated_masks, do_not_add_mask_to_memory=skip_add)
-            if ti + 1 < vid_length:                                  # decode + key-encode the next frame under this one
-                next_sample = vid_reader[ti + 1]
-                next_rgb = processor.prefetch_key(next_sample.rgb.pin_memory())
+            if len(pending) < key_batch:                             # decode + key-encode the next batch under this one
+                refill()
             done = fetcher.submit((sample, msk is not None), _post_process_gpu(sample, prob))
             total_time += perf_counter() - a
             for tag, out_mask in done:
