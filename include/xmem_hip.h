@@ -108,6 +108,13 @@ int xmem_add3(const float* a, const float* b, const float* c, float* y, size_t n
  * (util/tensor_util.py:47-61): left/top pads lw, lh; 4th channel zero. */
 int xmem_pack_image(const float* img, float* out, int H, int W, int Hp, int Wp, int lh, int lw, void* stream);
 
+/* Frame ingest on the device: decoded uint8 image [H][W][3] (RGB, HWC) -> the same padded NHWC4
+ * tensor, after transforms.ToTensor + im_normalization (inference/data/video_reader.py:61-76,
+ * dataset/range_transform.py:5-8): ((x / 255) - mean[c]) / std[c] in fp32, in that operation order.
+ * mean3_host / std3_host: 3 floats each, HOST pointers. */
+int xmem_pack_image_u8(const uint8_t* img, float* out, int H, int W, int Hp, int Wp, int lh, int lw,
+                       const float* mean3_host, const float* std3_host, void* stream);
+
 /* value-encoder input, model/network.py:73-81 + modules.py:126-131: per object k the 5 channels
  * (r,g,b,mask_k,sum_{j!=k} mask_j) padded to 8: image4 [Hp][Wp][4], masks [K][Hp][Wp] -> out [K][Hp][Wp][8] */
 int xmem_pack_value_input(const float* image4, const float* masks, float* out, int K, int Hp, int Wp, void* stream);

@@ -469,3 +469,27 @@ def test_affinity_large_memory(n, hw, nseg):
         q0 = int(pick[0])
         ref = (w[q0].unsqueeze(1) * V[idx[q0].cuda()].cpu()).sum(0)
         close(out[0, q0], ref, 1e-3, 1e-5, 'large-N readout')
+
+
+def test_pack_image_u8_matches_totensor_normalize():
+    """Device ingest (xmem_pack_image_u8) == ToTensor + Normalize + pad_divide_by on the host, bit for bit, and step() on a
+    uint8 H x W x 3 frame == step() on the reference-format float frame."""
+    from xmem2_amd import ops
+    from xmem2_amd.tensor_util import pad_amounts
+    g = torch.Generator().manual_seed(0)
+    H, W = 50, 70
+    u8 = torch.randint(0, 256, (H, W, 3), dtype=torch.uint8, generator=g)
+    u8[0, 0] = torch.tensor([0, 255, 128], dtype=torch.uint8)
+    mean = np.array(ops.IM_MEAN, np.float32); std = np.array(ops.IM_STD, np.float32)
+    want = (u8.numpy().astype(np.float32) / np.float32(255.0) - mean) / std                # H x W x 3
+    tw = (u8.permute(2, 0, 1).float().div(255)).sub_(torch.tensor(ops.IM_MEAN).view(3, 1, 1)).div_(torch.tensor(ops.IM_STD).view(3, 1, 1))
+    assert np.array_equal(want, tw.permute(1, 2, 0).numpy())                               # numpy == torchvision's op order
+    lw, uw, lh, uh = pad_amounts(H, W, 16)
+    got = ops.pack_image_u8(u8.cuda(), H + lh + uh, W + lw + uw, lh, lw).cpu().numpy()[0]
+    ref = np.zeros((H + lh + uh, W + lw + uw, 4), np.float32)
+    ref[lh:lh + H, lw:lw + W, :3] = want
+    assert np.array_equal(got, ref)
+    flt = ops.pack_image(tw.cuda().contiguous(), H + lh + uh, W + lw + uw, lh, lw).cpu().numpy()[0]
+    assert np.array_equal(got, flt)
+    with pytest.raises(RuntimeError):
+        ops.pack_image_u8(u8, 64, 80, 0, 0)                                                 # host tensor: no CPU path

@@ -136,3 +136,26 @@ def test_arena_store_bookkeeping_on_cpu():
     assert st.size == hw and float(st.key_rows()[0, 0]) == 300.0
     with pytest.raises(AssertionError):
         KeyValueMemoryStore(False).add(mk(hw, ck, 0), torch.zeros(2, hw, cv), None, None, [2, 1])
+
+
+def test_oracle_selector_properties():
+    """Candidate-selector restatement (frame_selection.py:99-244): D(A, A) = 0, D >= 0, a previously chosen frame is never
+    re-picked while another valid frame differs from it, frames with empty masks are ignored, alpha = 0 ignores masks."""
+    import torch
+    from oracle import cpu_ref as R
+    g = torch.Generator().manual_seed(0)
+    F_, h, w = 5, 4, 6
+    keys = torch.randn(F_, 64, h, w, generator=g) * 0.5
+    shr = 1 + torch.rand(F_, 1, h, w, generator=g)
+    sel = torch.rand(F_, 64, h, w, generator=g)
+    masks = [(torch.rand(1, 64, 96, generator=g) > 0.5).float() for _ in range(F_)]
+    assert float(R.cycle_dissimilarity(keys[1], shr[1], sel[1], keys[1], shr[1], sel[1])) == 0.0
+    assert float(R.cycle_dissimilarity(keys[1], shr[1], sel[1], keys[2], shr[2], sel[2])) > 0.0
+    picks = R.select_next_candidates(keys, shr, sel, masks, 3, previously_chosen_candidates=[0])
+    assert len(set(picks)) == 3 and 0 not in picks
+    assert R.select_next_candidates(keys, shr, sel, masks, 2, previously_chosen_candidates=[0], only_new_candidates=False)[0] == 0
+    empty = [m.clone() for m in masks]; empty[3].zero_()
+    assert 3 not in R.select_next_candidates(keys, shr, sel, empty, 3, previously_chosen_candidates=[0])
+    other = [(torch.rand(1, 64, 96, generator=g) > 0.3).float() for _ in range(F_)]
+    a0 = R.select_next_candidates(keys, shr, sel, masks, 2, alpha=0.0)
+    assert a0 == R.select_next_candidates(keys, shr, sel, other, 2, alpha=0.0)

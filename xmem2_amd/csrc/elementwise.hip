@@ -367,6 +367,34 @@ extern "C" int xmem_pack_image(const float* img, float* out, int H, int W, int H
     return xmem_check_launch();
 }
 
+// uint8 H x W x 3 frame as decoded -> ToTensor (x / 255) + Normalize ((x - mean) / std) + pad + NHWC4 in one pass
+// (inference/data/video_reader.py:61-76: transforms.ToTensor, im_normalization; dataset/range_transform.py:5-8).
+// Same fp32 operation order as torchvision: a correctly rounded division by 255, a subtraction, a division.
+__global__ void pack_image_u8_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int H, int W, int Hp, int Wp, int lh, int lw,
+                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int total = Hp * Wp;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int x = e % Wp, y = e / Wp;
+        const int sy = y - lh, sx = x - lw;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+            const uint8_t* px = img + ((size_t)sy * W + sx) * 3;
+            v.x = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[0], 255.0f), m0), s0);
+            v.y = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[1], 255.0f), m1), s1);
+            v.z = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[2], 255.0f), m2), s2);
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)e * 4) = v;
+    }
+}
+
+extern "C" int xmem_pack_image_u8(const uint8_t* img, float* out, int H, int W, int Hp, int Wp, int lh, int lw,
+                                  const float* mean3_host, const float* std3_host, void* stream) {
+    if (!img || !out || !mean3_host || !std3_host || H <= 0 || W <= 0 || Hp < H || Wp < W || lh < 0 || lw < 0) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_image_u8_kernel, dim3(grid_for((size_t)Hp * Wp)), dim3(256), 0, (hipStream_t)stream, img, out, H, W, Hp, Wp,
+                       lh, lw, mean3_host[0], mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
+    return xmem_check_launch();
+}
+
 __global__ void pack_value_input_kernel(const float* __restrict__ image4, const float* __restrict__ masks, float* __restrict__ out,
                                         int K, int P) {
     const size_t total = (size_t)K * P;

@@ -32,7 +32,8 @@ def _rgb_of(item):
         return item
     if isinstance(item, dict):
         return item['rgb']
-    return item.rgb
+    u8 = getattr(item, 'rgb_u8', None)           # this repo's reader: decoded uint8 frame, normalised on the device
+    return u8 if u8 is not None else item.rgb
 
 
 def extract_keys(dataloder, processor, print_progress=False, flatten=True, **kwargs):

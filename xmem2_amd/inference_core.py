@@ -56,11 +56,16 @@ class InferenceCore:
 
     # ---- helpers ---------------------------------------------------------------------------------
     def _pack(self, image):
-        if image.dim() != 3 or image.shape[0] != 3:
-            raise NotImplementedError('image must be 3 x H x W')
-        H, W = image.shape[-2:]
+        """3 x H x W float (the reference's normalised frame, inference_core.py:73-74) or - ingest on the device,
+        SURVEY 8f rank 2 - the decoded H x W x 3 uint8 frame, normalised here as video_reader.py:61-76 does."""
+        u8 = image.dtype == torch.uint8 and image.dim() == 3 and image.shape[2] == 3
+        if not u8 and (image.dim() != 3 or image.shape[0] != 3):
+            raise NotImplementedError('image must be 3 x H x W (float) or H x W x 3 (uint8)')
+        H, W = (image.shape[0], image.shape[1]) if u8 else image.shape[-2:]
         lw, uw, lh, uh = pad_amounts(H, W, 16)
         self.pad = (lw, uw, lh, uh)
+        if u8:
+            return ops.pack_image_u8(image, H + lh + uh, W + lw + uw, lh, lw), (H, W), (H + lh + uh, W + lw + uw)
         if image.dtype != torch.float32:
             image = image.float()
         return ops.pack_image(image, H + lh + uh, W + lw + uw, lh, lw), (H, W), (H + lh + uh, W + lw + uw)

@@ -277,6 +277,22 @@ def pack_image(img, Hp, Wp, lh, lw):
     return out
 
 
+IM_MEAN = (0.485, 0.456, 0.406)      # dataset/range_transform.py:5-8
+IM_STD = (0.229, 0.224, 0.225)
+
+
+def pack_image_u8(img, Hp, Wp, lh, lw, mean=IM_MEAN, std=IM_STD):
+    """decoded frame uint8 [H,W,3] -> normalised, zero padded [1,Hp,Wp,4] (ToTensor + Normalize + pad in one kernel)."""
+    if not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+        raise RuntimeError('pack_image_u8: expected a CUDA (HIP) uint8 tensor of shape [H, W, 3]')
+    if not img.is_contiguous():
+        img = img.contiguous()
+    out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img.device)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(load().xmem_pack_image_u8(ptr(img), ptr(out), img.shape[0], img.shape[1], Hp, Wp, lh, lw, m3, s3, stream_ptr()))
+    return out
+
+
 def pack_value_input(image4, masks):
     """image4 [1,Hp,Wp,4], masks [K,Hp,Wp] -> [K,Hp,Wp,8]."""
     K, Hp, Wp = masks.shape

