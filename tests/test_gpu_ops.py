@@ -385,6 +385,31 @@ def test_affinity_ties_are_exact():
         assert len(set(idx[q].tolist())) == 30
 
 
+def test_affinity_optimistic_overflow_falls_back_exactly():
+    """>56 near-duplicates of a query inside one split of a large memory overflow the optimistic candidate buffers; the
+    flagged query tiles are redone by the safe kernel (global-scratch buffers) and the result stays exact."""
+    from xmem2_amd import ops
+    gen = g_(77)
+    n, hw = 16384, 200
+    mk = torch.randn(n, 64, generator=gen) * 0.9
+    ms = torch.rand(n, generator=gen) + 1
+    qk = torch.randn(hw, 64, generator=gen) * 0.9
+    qe = torch.rand(hw, 64, generator=gen) * 0.9 + 0.05
+    for j, q in enumerate((3, 70, 150)):                       # three queries in three different query tiles
+        lo = 2000 + 4000 * j
+        mk[lo:lo + 120] = qk[q] + torch.randn(120, 64, generator=gen) * 0.02
+    w, idx, sims = ops.affinity_topk([(mk.cuda(), ms.cuda())], qk.cuda(), qe.cuda(), 30, want_sim=True)
+    sim = R.get_similarity(mk.t().unsqueeze(0), ms.view(1, 1, -1), qk.t().unsqueeze(0), qe.t().unsqueeze(0))[0]   # [n, hw]
+    rv, ri = torch.topk(sim, 30, dim=0)
+    close(sims, rv.t(), 1e-4, 1e-4, 'top-k values after fallback')
+    for q in (3, 70, 150, 0, 199):
+        assert set(idx[q].tolist()) == set(ri[:, q].tolist())
+    aff = R.do_softmax(sim.unsqueeze(0), top_k=30)[0]            # [n, hw]
+    dense = torch.zeros(hw, n)
+    dense.scatter_(1, idx.cpu().long(), w.cpu())
+    close(dense, aff.t(), 2e-4, 1e-7, 'affinity after fallback')
+
+
 # ---------------------------------------------------------------------------------------------------------
 # consolidation kernels
 # ---------------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ from xmem2_amd.synth import synthetic_state_dict, synthetic_frames, synthetic_ma
 import bench
 cfg = bench.b32_config()
 net = XMem(dict(cfg), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
-fr = torch.from_numpy(synthetic_frames(34, 480, 854)).cuda(); mk = torch.from_numpy(synthetic_masks(34, 1, 480, 854)).cuda()
+fr = torch.from_numpy(synthetic_frames(64, 480, 854)).cuda(); mk = torch.from_numpy(synthetic_masks(64, 1, 480, 854)).cuda()
 core = InferenceCore(net, cfg); core.set_all_labels([1])
 for j in range(32):
     core.put_to_permanent_memory(fr[j], mk[j])
@@ -31,3 +31,18 @@ for _ in range(20):
     ops.affinity_topk(segs, qk, qe, 30)
 e1.record(); e1.synchronize()
 print(f'affinity on real keys: {e0.elapsed_time(e1) * 50:.1f} us per call')
+
+# every query frame of the bench clip: worst (split, query) candidate count and time per call
+perm = core.memory.permanent_work_mem
+segs = [(perm.key_rows(), perm.shrinkage_rows())]
+for f in range(32, 64):
+    key, shr, sel = core.encode_frame_key(fr[f])
+    qk = key[0].permute(1, 2, 0).reshape(-1, 64).contiguous(); qe = sel[0].permute(1, 2, 0).reshape(-1, 64).contiguous()
+    ops.affinity_topk(segs, qk, qe, 30); torch.cuda.synchronize()
+    ws = ops._workspaces[(str(qk.device), 'affinity')]
+    cnt = ws[cnt_off:cnt_off + 64 * HW * 4].view(torch.int32).view(64, HW)[:19].cpu()
+    e0.record()
+    for _ in range(5):
+        ops.affinity_topk(segs, qk, qe, 30)
+    e1.record(); e1.synchronize()
+    print(f'frame {f}: per (split,query) max {int(cnt.max())}, queries with a split > 40: {int((cnt.max(0).values > 40).sum())}, total/query mean {cnt.sum(0).float().mean():.1f} max {int(cnt.sum(0).max())}; {e0.elapsed_time(e1) * 200:.0f} us')

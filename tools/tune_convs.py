@@ -7,7 +7,7 @@ from xmem2_amd import ops, XMem, InferenceCore
 from xmem2_amd.synth import synthetic_state_dict, synthetic_frames, synthetic_masks
 import bench
 
-ops._plans = {}            # ignore shipped plans: re-measure everything
+ops._plans = {} if os.environ.get('XMEM_RETUNE_ALL') else ops._load_plans()   # default: keep shipped plans, add new shapes
 net = XMem(dict(bench.b32_config()), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
 net.use_graphs = False
 for (H, W, K) in [(480, 854, 1), (480, 854, 2), (720, 1280, 1)]:
@@ -17,6 +17,10 @@ for (H, W, K) in [(480, 854, 1), (480, 854, 2), (720, 1280, 1)]:
     core.put_to_permanent_memory(fr[0], mk[0])
     for t in range(1, 4):
         core.step(fr[t], None, None)
+    if K == 1:                                   # batched key-encoder hints (prefetch_keys): batch shapes incl. skip convs
+        for B in (2, 4, 8):
+            img = torch.zeros(B, (H + 15) // 16 * 16, (W + 15) // 16 * 16, 4, device='cuda')
+            net._encode_key_eager(img, True, True, False, True)
     torch.cuda.synchronize()
     print(H, W, K, 'plans so far', len(ops._tuned_now))
 n = ops.dump_tuned_plans(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/conv_plans.json')

@@ -50,6 +50,7 @@ struct AffArgs {
     u64* part_key; int* part_cnt;    // select pass output: [splits][HW][AFF_OUTCAP], [splits][HW]
     float* bound_part;               // bound pass output: [splits][HW][AFF_BOUND_SLOTS]
     int* ovf;                        // [query tiles] overflow flags of the optimistic select pass
+    u64* cand_spill;                 // MODE 3: [splits][query tiles][64][cap] global candidate buffers
 };
 
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -94,11 +95,16 @@ __device__ __forceinline__ void rerank(u64* ck, int c, int top_k, float* tau_q, 
 // MODE 0: bound pass.  MODE 1: optimistic select (small candidate buffers, no re-rank, no barriers in the tile loop,
 // two workgroups per CU; a buffer overflow raises ovf[query tile]).  MODE 2: safe select (worst-case buffers +
 // re-rank valve); when p.ovf is set it only re-does query tiles whose optimistic pass overflowed.
+// MODE 3: the safe select as the fallback of the optimistic pass: its worst-case candidate buffers live in GLOBAL
+// scratch (p.cand_spill), so the launch asks for 34 KB of LDS instead of 148 KB.  Nearly all of its workgroups return
+// at the flag test, and with the big allocation they could not even START while another stream's kernels held LDS
+// (measured: 90 us per frame of pure scheduling stall under the pipelined key encoder).
 template <int CK, int MODE>
 __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffArgs p) {
     static_assert(CK == 64, "kernel is specialised for C_k = 64");
     constexpr bool BOUND = (MODE == 0);
-    constexpr bool SAFE = (MODE == 2);
+    constexpr bool SAFE = (MODE >= 2);
+    constexpr bool SPILL = (MODE == 3);
     if (SAFE && p.ovf && p.ovf[blockIdx.x] == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bq = smem;                               // [64][132]
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffA
     float* tau = bsq + AFF_BQ;                      // [64]
     int* cnt = reinterpret_cast<int*>(tau + AFF_BQ);  // [64]
     u64* cand = reinterpret_cast<u64*>(cnt + AFF_BQ + 4);  // [64][cap]   (select pass only); cnt[64..67]: flag + pad
+    if (SPILL) cand = p.cand_spill + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)AFF_BQ * p.cap);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -464,7 +471,7 @@ inline int bound_stride(int total_tiles) {
     return total_tiles >= 256 ? 4 : 1;
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, total; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, spill_off, total; };
 WsLayout ws_layout(int HW) {
     WsLayout w;
     w.key_off = 0;
@@ -472,7 +479,10 @@ WsLayout ws_layout(int HW) {
     w.bound_off = w.cnt_off + align_up((size_t)64 * HW * sizeof(int), 256);
     w.tau_off = w.bound_off + align_up((size_t)16 * HW * AFF_BOUND_SLOTS * sizeof(float), 256);
     w.ovf_off = w.tau_off + align_up((size_t)HW * sizeof(float), 256);
-    w.total = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
+    w.spill_off = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
+    // fallback buffers: one per workgroup of the select grid (query tiles x splits <= max(512, query tiles)), cap = 96 + 128
+    const size_t wgs = cdiv(HW, AFF_BQ) > 512 ? (size_t)cdiv(HW, AFF_BQ) : 512;
+    w.total = w.spill_off + wgs * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64);
     return w;
 }
 }  // namespace
@@ -515,6 +525,7 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     const int R = bound_stride(tiles);
     a.tau_init = nullptr;
     a.ovf = nullptr;
+    a.cand_spill = nullptr;
     if (R > 1) {
         AffPlan pa = aff_plan(cdiv(tiles, R), HW, top_k, true);
         a.cap = 0; a.limit = 0; a.splits = pa.splits; a.tiles_per_split = pa.tiles_per_split; a.sub_tiles = pa.sub_tiles;
@@ -539,10 +550,18 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }
     a.cap = pl.cap;
-    auto kern = affinity_kernel<64, 2>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
-        return XMEM_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
+    if (a.ovf) {
+        // fallback of the optimistic pass: global candidate buffers, small LDS footprint (see MODE 3)
+        if ((size_t)cdiv(HW, AFF_BQ) * pl.splits * AFF_BQ * pl.cap * sizeof(u64) > wl.total - wl.spill_off) return XMEM_ERR_WORKSPACE;
+        a.cand_spill = reinterpret_cast<u64*>(ws + wl.spill_off);
+        const size_t lds3 = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float);
+        hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), lds3, s, a);
+    } else {
+        auto kern = affinity_kernel<64, 2>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+            return XMEM_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
+    }
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     const size_t mlds = ((size_t)pl.splits * AFF_OUTCAP + 2) * sizeof(u64) + (size_t)2 * top_k * sizeof(float);
     hipLaunchKernelGGL(affinity_merge_kernel, dim3(HW), dim3(64), mlds, s, a.part_key, a.part_cnt, pl.splits, HW, top_k,
