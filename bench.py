@@ -225,10 +225,23 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # control plane only (timing barrier + max / sum of two scalars): RCCL by default
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        backend = args.dist_backend
+        if backend == 'nccl':
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)                       # fail here, on every rank alike, rather than mid-measurement
+                torch.cuda.synchronize(device)
+            except Exception as e:                           # RCCL unusable on this node: the control plane falls back to gloo
+                print(f'[bench] rank {rank}: RCCL control plane failed ({type(e).__name__}: {e}); using gloo', file=sys.stderr)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)
+                backend = 'gloo'
+        if backend != 'nccl':
+            dist.init_process_group(backend, rank=rank, world_size=world)
     res = run_gpu(args, device, rank, world)
     elapsed = max_over_ranks(res['elapsed'], device)
     total_frames = sum_over_ranks(args.steps, device)

@@ -20,7 +20,7 @@ HW = qk.shape[0]
 w, idx, sim = ops.affinity_topk(segs, qk, qe, 30, want_sim=True)
 torch.cuda.synchronize()
 ws = ops._workspaces[(str(qk.device), 'affinity')]
-cnt_off = (64 * HW * 64 * 8 + 255) // 256 * 256
+cnt_off = (64 * HW * 88 * 8 + 255) // 256 * 256
 cnt = ws[cnt_off:cnt_off + 64 * HW * 4].view(torch.int32).view(64, HW)[:19].cpu()
 tot = cnt.sum(0).float()
 print(f'candidates per query: mean {tot.mean():.1f} max {tot.max():.0f} min {tot.min():.0f}; per (split,query) max {int(cnt.max())}')

@@ -29,9 +29,11 @@
 #define AFF_ROWS 32        // memory rows per wave tile
 #define AFF_STEP_ROWS 128  // rows per step (4 waves)
 #define AFF_MAXU 4         // candidate entries per lane during a re-rank (cap <= 256)
-#define AFF_OUTCAP 64      // candidates a (split, query) hands to the merge kernel
+#define AFF_OUTCAP 88      // candidates a (split, query) hands to the merge kernel
+#define AFF_MAX_TOPK 64
 #define AFF_BOUND_M 1      // survivors per lane and query in the bound pass
 #define AFF_BOUND_SLOTS (8 * AFF_BOUND_M)   // per (split, query): 4 waves x 2 half-waves x M
+#define AFF_MAX_BOUND_SPLITS 64
 
 typedef unsigned long long u64;
 
@@ -43,6 +45,8 @@ struct AffArgs {
     const float* qk; const float* qe;
     int HW, top_k, cap, limit;
     int splits, tiles_per_split;
+    int chunk;                       // > 0: tiles are dealt to the splits in chunks of this many (round-robin); 0: contiguous ranges
+    int merge_splits;                // MODE 3: number of per-split lists the merge kernel will read (>= splits)
     int tile_stride;                 // visit tiles 0, R, 2R, ...
     int sub_tiles;                   // ceil(total_tiles / tile_stride)
     const float* tau_init;           // [HW] lower bound of the k-th value (select pass) or NULL
@@ -152,11 +156,20 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffA
     }
     __syncthreads();
 
-    const int t_begin = split * p.tiles_per_split;                       // in units of visited (sub-sampled) tiles
-    const int t_end = min(p.sub_tiles, t_begin + p.tiles_per_split);
+    // Split -> tiles.  Default: split s owns the contiguous range [s*tps, (s+1)*tps).  Large memories (p.chunk > 0) deal
+    // chunks of ~half a memory frame round-robin to the splits instead: neighbouring frames are similar, so a query's best
+    // matches cluster in time, and with contiguous ranges they piled up in the candidate buffers of one split.
+    const int t_begin = p.chunk ? 0 : split * p.tiles_per_split;         // in units of visited (sub-sampled) tiles
+    const int t_end = p.chunk ? p.tiles_per_split : min(p.sub_tiles, t_begin + p.tiles_per_split);
 
     auto tile_info = [&](int tile, const float*& key, const float*& shr, int& segn, int& base, int& row0) -> bool {
-        if (tile >= t_end) { key = nullptr; shr = nullptr; segn = 0; base = 0; row0 = 0; return false; }
+        bool off = tile >= t_end;
+        if (p.chunk && !off) {
+            const int ci = tile / p.chunk, wi = tile - ci * p.chunk;
+            tile = (ci * p.splits + split) * p.chunk + wi;
+            off = tile >= p.sub_tiles;
+        }
+        if (off) { key = nullptr; shr = nullptr; segn = 0; base = 0; row0 = 0; return false; }
         tile *= p.tile_stride;
         int s = 0;
 #pragma unroll
@@ -334,6 +347,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffA
         const size_t o = (size_t)split * p.HW + qg;
         if (lane == 0) p.part_cnt[o] = c;
         for (int s = lane; s < c; s += 64) p.part_key[o * AFF_OUTCAP + s] = cand[(size_t)q * p.cap + s];
+        if (SPILL && lane == 0)                   // the fallback grid has fewer splits than the optimistic pass it replaces:
+            for (int s2 = split + p.splits; s2 < p.merge_splits; s2 += p.splits) p.part_cnt[(size_t)s2 * p.HW + qg] = 0;
     }
 }
 
@@ -382,7 +397,7 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
     const int excl = incl - my_c;
     for (int s = 0; s < splits; ++s) {
         const int c = __shfl(my_c, s, 64), off = __shfl(excl, s, 64);
-        if (lane < c) keys[off + lane] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + lane];
+        for (int e = lane; e < c; e += 64) keys[off + e] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + e];
     }
     // pre-filter: the top_k-th largest of the 64 lane-local maxima is reached by >= top_k candidates, so everything
     // below it can be dropped before the O(T^2/64) exact ranking (tames queries with several hundred survivors)
@@ -437,7 +452,7 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
 namespace {
 struct AffPlan { int splits, tiles_per_split, sub_tiles, limit, cap; size_t lds; };
 
-AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound) {
+AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound, int n_rows = 0) {
     AffPlan pl;
     pl.sub_tiles = sub_tiles;
     const int qtiles = cdiv(HW, AFF_BQ);
@@ -445,11 +460,31 @@ AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound) {
     if (bound) {
         s = 512 / qtiles;                        // small LDS: two workgroups per CU
         if (s > 16) s = 16;                      // keeps the survivor list of the bound reduction short
+        // The bound is the k-th largest of one survivor per lane group (8 groups per split), so it is only tight while the
+        // best matches of different memory frames fall into different groups: keep ~4 groups per memory frame
+        // (32 frames -> 16 splits; 256 frames at 8 splits let ~1000 candidates per query through and overflowed every frame).
+        const int frames = n_rows / (HW > 0 ? HW : 1);
+        int want = frames / 2;
+        if (want > AFF_MAX_BOUND_SPLITS) want = AFF_MAX_BOUND_SPLITS;
+        if (want > s) s = want;
     } else {
-        // one workgroup per CU (LDS bound): aim for <= 2 full rounds of the 256 CUs, >= 16 tiles (4 steps) per split
+        // two workgroups per CU: aim for whole rounds of the 512 slots, >= 16 tiles (4 steps) per split
         s = 512 / qtiles;
         if (s < 1) s = 1;
         if (sub_tiles / s < 16) s = 256 / qtiles;
+        if (s < 16 && sub_tiles / 16 >= 16) {
+            // many query tiles (HW > 2048): the candidates a query keeps (~ R*k, far more in low-texture regions) must
+            // still spread over enough splits to fit the optimistic buffers - with 512/qtiles = 8 splits the 720p / 256-frame
+            // configuration overflowed on every frame.  Smallest s >= 16 that fills its last round of slots >= 90 %.
+            int best = 16; double best_eff = 0.0;
+            for (int c = 16; c <= 32 && sub_tiles / c >= 16; ++c) {
+                const long wgs = (long)qtiles * c;
+                const double eff = (double)wgs / (double)(((wgs + 511) / 512) * 512);
+                if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+                if (eff >= 0.9) { best = c; break; }
+            }
+            s = best;
+        }
     }
     if (s < 1) s = 1;
     int maxs = sub_tiles / 8; if (maxs < 1) maxs = 1;
@@ -463,7 +498,8 @@ AffPlan aff_plan(int sub_tiles, int HW, int top_k, bool bound) {
     return pl;
 }
 
-#define AFF_OPT_CAP 56     // optimistic candidate buffer (expected fill ~ R*k/splits = 6, observed max 39): 28.7 KB -> two workgroups per CU
+#define AFF_OPT_CAP 88     // optimistic candidate buffer (expected fill ~ R*k/splits = 6..8, observed max 54 on redundant memories):
+                           // 45 KB + 33.8 KB of query operand = 78.9 KB -> still two workgroups per 160 KB CU
 inline size_t opt_lds() { return ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float) + (size_t)AFF_BQ * AFF_OPT_CAP * sizeof(u64); }
 
 inline int bound_stride(int total_tiles) {
@@ -477,7 +513,7 @@ WsLayout ws_layout(int HW) {
     w.key_off = 0;
     w.cnt_off = align_up((size_t)64 * HW * AFF_OUTCAP * sizeof(u64), 256);
     w.bound_off = w.cnt_off + align_up((size_t)64 * HW * sizeof(int), 256);
-    w.tau_off = w.bound_off + align_up((size_t)16 * HW * AFF_BOUND_SLOTS * sizeof(float), 256);
+    w.tau_off = w.bound_off + align_up((size_t)AFF_MAX_BOUND_SPLITS * HW * AFF_BOUND_SLOTS * sizeof(float), 256);
     w.ovf_off = w.tau_off + align_up((size_t)HW * sizeof(float), 256);
     w.spill_off = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
     // fallback buffers: one per workgroup of the select grid (query tiles x splits <= max(512, query tiles)), cap = 96 + 128
@@ -497,7 +533,7 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
                                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!segs || n_seg <= 0 || n_seg > XMEM_MAX_SEGMENTS || !qk || !out_w || !out_idx || HW <= 0) return XMEM_ERR_BAD_ARG;
     if (Ck != 64) return XMEM_ERR_UNSUPPORTED;
-    if (top_k < 1 || top_k > AFF_OUTCAP) return XMEM_ERR_UNSUPPORTED;
+    if (top_k < 1 || top_k > AFF_MAX_TOPK) return XMEM_ERR_UNSUPPORTED;
     AffArgs a;
     int tiles = 0, base = 0, ns = 0;
     for (int i = 0; i < n_seg; ++i) {
@@ -527,9 +563,9 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     a.ovf = nullptr;
     a.cand_spill = nullptr;
     if (R > 1) {
-        AffPlan pa = aff_plan(cdiv(tiles, R), HW, top_k, true);
+        AffPlan pa = aff_plan(cdiv(tiles, R), HW, top_k, true, base);
         a.cap = 0; a.limit = 0; a.splits = pa.splits; a.tiles_per_split = pa.tiles_per_split; a.sub_tiles = pa.sub_tiles;
-        a.tile_stride = R;
+        a.tile_stride = R; a.chunk = 0;
         hipLaunchKernelGGL((affinity_kernel<64, 0>), dim3(cdiv(HW, AFF_BQ), pa.splits), dim3(256), pa.lds, s, a);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         const int T = pa.splits * AFF_BOUND_SLOTS;
@@ -541,21 +577,40 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     AffPlan pl = aff_plan(tiles, HW, top_k, false);
     a.limit = pl.limit; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
     a.tile_stride = 1;
+    a.chunk = 0;
+    {
+        // chunked round-robin only when every split gets >= 16 chunks (load imbalance <= 1/16)
+        int ch = cdiv(HW, AFF_ROWS) / 2; if (ch < 8) ch = 8;
+        const int n_chunks = cdiv(pl.sub_tiles, ch);
+        if (n_chunks >= 16 * pl.splits) {
+            a.chunk = ch;
+            a.tiles_per_split = cdiv(n_chunks, pl.splits) * ch;       // local visit indices per split (some map past the end)
+        }
+    }
     if (R > 1 && top_k <= AFF_OPT_CAP) {
         // optimistic select with the bound in hand, then the safe kernel on the (normally zero) overflowed query tiles
         a.ovf = reinterpret_cast<int*>(ws + wl.ovf_off);
         if (hipMemsetAsync(a.ovf, 0, (size_t)cdiv(HW, AFF_BQ) * sizeof(int), s) != hipSuccess) return XMEM_ERR_LAUNCH;
         a.cap = AFF_OPT_CAP;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)opt_lds()) != hipSuccess) return XMEM_ERR_LAUNCH;
         hipLaunchKernelGGL((affinity_kernel<64, 1>), dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), opt_lds(), s, a);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }
     a.cap = pl.cap;
+    a.merge_splits = pl.splits;
     if (a.ovf) {
-        // fallback of the optimistic pass: global candidate buffers, small LDS footprint (see MODE 3)
-        if ((size_t)cdiv(HW, AFF_BQ) * pl.splits * AFF_BQ * pl.cap * sizeof(u64) > wl.total - wl.spill_off) return XMEM_ERR_WORKSPACE;
+        // fallback of the optimistic pass: global candidate buffers, small LDS footprint (see MODE 3); its own, coarser
+        // split count keeps the scratch at <= max(512, query tiles) buffers (efficiency is irrelevant on this rare path)
+        const int qtiles = cdiv(HW, AFF_BQ);
+        int fs = 512 / qtiles; if (fs < 1) fs = 1; if (fs > pl.splits) fs = pl.splits;
+        a.chunk = 0;
+        a.tiles_per_split = cdiv(pl.sub_tiles, fs);
+        a.splits = cdiv(pl.sub_tiles, a.tiles_per_split);
+        if ((size_t)qtiles * a.splits * AFF_BQ * pl.cap * sizeof(u64) > wl.total - wl.spill_off) return XMEM_ERR_WORKSPACE;
         a.cand_spill = reinterpret_cast<u64*>(ws + wl.spill_off);
         const size_t lds3 = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float);
-        hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), lds3, s, a);
+        hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(qtiles, a.splits), dim3(256), lds3, s, a);
     } else {
         auto kern = affinity_kernel<64, 2>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
