@@ -558,7 +558,15 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     float* tau0 = reinterpret_cast<float*>(ws + wl.tau_off);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    const int R = bound_stride(tiles);
+    int R = bound_stride(tiles);
+    AffPlan pl = aff_plan(tiles, HW, top_k, false);
+    // large memories: chunks of ~half a memory frame are dealt round-robin to the select splits (see the kernel), but only
+    // when every split gets >= 16 chunks (load imbalance <= 1/16)
+    int sel_chunk = cdiv(HW, AFF_ROWS) / 2; if (sel_chunk < 8) sel_chunk = 8;
+    const int n_chunks = cdiv(pl.sub_tiles, sel_chunk);
+    if (n_chunks < 16 * pl.splits) sel_chunk = 0;
+    // with the candidates spread evenly the looser bound of an every-8th-tile sample still fits the buffers (12.5 % extra work)
+    if (sel_chunk && tiles >= 8192) R = 8;
     a.tau_init = nullptr;
     a.ovf = nullptr;
     a.cand_spill = nullptr;
@@ -574,19 +582,10 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         a.tau_init = tau0;
     }
-    AffPlan pl = aff_plan(tiles, HW, top_k, false);
     a.limit = pl.limit; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
     a.tile_stride = 1;
-    a.chunk = 0;
-    {
-        // chunked round-robin only when every split gets >= 16 chunks (load imbalance <= 1/16)
-        int ch = cdiv(HW, AFF_ROWS) / 2; if (ch < 8) ch = 8;
-        const int n_chunks = cdiv(pl.sub_tiles, ch);
-        if (n_chunks >= 16 * pl.splits) {
-            a.chunk = ch;
-            a.tiles_per_split = cdiv(n_chunks, pl.splits) * ch;       // local visit indices per split (some map past the end)
-        }
-    }
+    a.chunk = sel_chunk;
+    if (sel_chunk) a.tiles_per_split = cdiv(n_chunks, pl.splits) * sel_chunk;   // local visit indices per split (some map past the end)
     if (R > 1 && top_k <= AFF_OPT_CAP) {
         // optimistic select with the bound in hand, then the safe kernel on the (normally zero) overflowed query tiles
         a.ovf = reinterpret_cast<int*>(ws + wl.ovf_off);
