@@ -253,6 +253,15 @@ def main():
         aff = prof.get('affinity', dict(ms=0.0, flop=0.0, launches=0))
         conv_tflops = conv['flop'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else None
         aff_tflops = aff['flop'] / (aff['ms'] * 1e-3) / 1e12 if aff['ms'] > 0 else None
+        # HBM-side traffic per frame of the kernel families: PMC counters need rocprofv3 around the process, so bench.py
+        # reports the committed measurement of this same command (profiles/, separate --pmc passes, gfx950 correction)
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_bench_b32_pmc_per_frame.json')) as f:
+                fam = json.load(f)['families']
+            traffic = {k: v['read_bytes'] + v['write_bytes'] for k, v in fam.items()}
+        except Exception:
+            pass
         line = {
             'metric': 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference',
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -263,8 +272,9 @@ def main():
                        'replica_streams': world, 'top_k': TOPK, 'frame_pipelining': (not args.no_prefetch), 'key_batch': (args.key_batch if not args.no_prefetch else 0), 'parallelism': f'{world} independent streams, no collectives'},
             'roofline': {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel (implicit GEMM / Winograd-domain GEMM, fp32 MFMA) + transforms',
                          'achieved': conv_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (conv_tflops / PEAK_FP32_MFMA_TFLOPS) if conv_tflops else None, 'traffic': None,
-                         'measured': 'HIP events, each distinct launch of one frame timed over 10 back-to-back repetitions (includes the Winograd transform kernels of a convolution call)',
+                         'frac': (conv_tflops / PEAK_FP32_MFMA_TFLOPS) if conv_tflops else None, 'traffic': traffic.get('conv'),
+                         'traffic_unit': 'HBM-side bytes per frame of these launches (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_b32_pmc_per_frame.json)',
+                         'measured': 'HIP events on the launch stream: every distinct convolution launch of one frame (un-hinted, batch-1 key encoder) timed over 10 back-to-back repetitions, Winograd transform kernels included; the timed region itself replays HIP graphs on two streams with batch-4 key passes',
                          'launches_per_frame': conv['launches'] / max(res['prof_frames'], 1),
                          'kernel_ms_per_frame': conv['ms'] / max(res['prof_frames'], 1),
                          'algorithmic_gflop_per_frame': conv['flop'] / 1e9 / max(res['prof_frames'], 1)},
@@ -272,7 +282,7 @@ def main():
                                   'achieved': aff_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': (aff_tflops / PEAK_FP32_MFMA_TFLOPS) if aff_tflops else None,
                                   'kernel_ms_per_frame': aff['ms'] / max(res['prof_frames'], 1),
-                                  'algorithmic_gflop_per_frame': alg['similarity']},
+                                  'algorithmic_gflop_per_frame': alg['similarity'], 'traffic': traffic.get('affinity')},
             'frame_gflop': alg, 'whole_frame_tflops': alg['total'] / 1e3 * fps / world,
             'preload_s_per_rank': res['preload_s'],
         }

@@ -233,3 +233,40 @@ def test_prefetch_keys_is_only_a_hint(hip_net):
         assert float((ops.argmax_u8(a) != ops.argmax_u8(b)).float().mean()) < 1e-4
     with pytest.raises(ValueError):
         c.prefetch_keys([fr[0], fr[1][:, :64]])
+
+
+@pytest.mark.parametrize('hw,n_obj,perm,steps', [((720, 1280), 1, 3, 3), ((1080, 1920), 2, 1, 2)],
+                         ids=['720p_1obj', '1080p_2obj'])
+def test_e2e_large_frames_vs_oracle(hip_net, ref_net, hw, n_obj, perm, steps):
+    """BASELINE configs 4 / 5 frame geometry (720p, 1080p -> padded 1088 x 1920) end to end against the oracle on a few
+    frames: permanent preload, batched key hints, one memory frame, 1-2 objects.  Same acceptance as the 480p clips."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    t = perm + steps
+    frames = T(synthetic_frames(t, *hw)); masks = T(synthetic_masks(t, n_obj, *hw))
+    cfg = base_config(mem_every=2)
+    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
+    labels = list(range(1, n_obj + 1))
+    for c in (core, ref):
+        c.set_all_labels(labels)
+    for j in range(perm):
+        core.put_to_permanent_memory(frames[j].cuda(), masks[j].cuda())
+        ref.put_to_permanent_memory(frames[j], masks[j])
+    dev = [frames[perm + i].cuda() for i in range(steps)]
+    core.prefetch_keys(dev)                                    # one batched key-encoder hint for all query frames
+    inter = uni = mism = 0
+    for i in range(steps):
+        p = core.step(dev[i], None, None)
+        q = ref.step(frames[perm + i], None, None)
+        assert p.shape == q.shape == (n_obj + 1,) + tuple(hw)
+        a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
+        mism += int((a != b).sum())
+        inter += int(((a > 0) & (b > 0) & (a == b)).sum()); uni += int(((a > 0) | (b > 0)).sum())
+        assert float((p.cpu() - q).abs().mean()) < 5e-4
+        m, rm = core.memory, ref.memory
+        assert (m.temporary_work_mem.size, m.permanent_work_mem.size) == (rm.temporary_work_mem.size, rm.permanent_work_mem.size)
+    iou = inter / max(uni, 1)
+    print(f'{hw}: IoU {iou:.5f}, argmax mismatch {mism}/{steps * hw[0] * hw[1]}')
+    assert iou >= 0.999 and mism / (steps * hw[0] * hw[1]) < 1e-4
