@@ -65,6 +65,8 @@ typedef struct {
                            13..15 = fused Winograd GEMM + output transform, tiles {128x64, 64x64, 64x128} */
     int plan_splitk;    /* 0 = heuristic; >0 = number of K splits */
     const float* w_winograd; /* optional [16][Cout][Cin]: G g G^T of the 3x3 filter (3x3 / stride 1 / pad 1 only) */
+    int res_broadcast;  /* 1: res is ONE image [Ho][Wo][ldres] added to every batch element (the per-object halves of the
+                           fuser convolutions share the f16 half, model/modules.py:31-41 on cat([x, g])) */
 } xmem_conv_desc;
 
 size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);

@@ -496,6 +496,30 @@ def test_affinity_large_memory(n, hw, nseg):
         close(out[0, q0], ref, 1e-3, 1e-5, 'large-N readout')
 
 
+@pytest.mark.parametrize('plan', [(0, 0), (3, 1), (6, 2), (9, 1), (14, 1)], ids=['auto', 'direct', 'splitk', 'winograd', 'wino_fused'])
+def test_conv_broadcast_residual_and_channel_slice_input(plan):
+    """res_broadcast: one [1,Ho,Wo,C] image added to every batch element; input = a channel slice of a wider buffer
+    (the per-object half of the fuser convolutions): equals the convolution over the concatenation."""
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    gen = g_(91)
+    K, h, w, cx, cg, co = 3, 12, 20, 64, 96, 64
+    x = torch.randn(1, h, w, cx, generator=gen)
+    g = torch.randn(K, h, w, cg, generator=gen)
+    wt = torch.randn(co, cx + cg, 3, 3, generator=gen) * 0.05
+    bias = torch.randn(co, generator=gen)
+    cat = torch.cat([x.expand(K, -1, -1, -1), g], 3)                                   # [K,h,w,cx+cg]
+    ref = F.conv2d(F.relu(cat.permute(0, 3, 1, 2)), wt, bias, padding=1).relu().permute(0, 2, 3, 1)
+    wk = wt.permute(0, 2, 3, 1).contiguous().cuda()
+    ones, zeros = torch.ones(co).cuda(), torch.zeros(co).cuda()
+    wx = ConvWeights(wk[..., :cx].contiguous(), ones, zeros, 1, 1)
+    wg = ConvWeights(wk[..., cx:].contiguous(), ones, bias.cuda(), 1, 1)
+    catd = cat.cuda().contiguous()
+    sx = ops.conv2d(x.cuda(), wx, relu_in=True, plan=plan)
+    got = ops.conv2d(catd[..., cx:], wg, relu_in=True, relu_out=True, res=sx, res_broadcast=True, in_ld=cx + cg, cin=cg, plan=plan)
+    close(got, ref, 2e-4, 2e-4, f'broadcast residual plan {plan}')
+
+
 def test_pack_image_u8_matches_totensor_normalize():
     """Device ingest (xmem_pack_image_u8) == ToTensor + Normalize + pad_divide_by on the host, bit for bit, and step() on a
     uint8 H x W x 3 frame == step() on the reference-format float frame."""

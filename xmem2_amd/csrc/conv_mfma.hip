@@ -29,6 +29,7 @@ struct ConvArgs {
     int nk, splitk, kt_per_split;
     int tiles_m, tiles_n;
     int raw;                                   // 1: store the bare accumulator (Winograd-domain GEMM)
+    int res_mod;                               // > 0: residual is one image broadcast over the batch (pixel index mod Ho*Wo)
     long in_gstride, w_gstride, out_gstride;   // blockIdx.y = group (the 16 Winograd tile positions), floats
 };
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     gout[(size_t)m * p.ldout + n] = v;
                 } else if (p.splitk == 1) {
                     v = v * sc + sh;
-                    if (p.res) v += p.res[(size_t)m * p.ldres + n];
+                    if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres + n];
                     if (p.relu_out) v = fmaxf(v, 0.f);
                     gout[(size_t)m * p.ldout + n] = v;
                 } else {
@@ -207,7 +208,7 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs p) {
         float v = 0.f;
         for (int z = 0; z < p.splitk; ++z) v += p.partial[(size_t)z * total + e];
         v = v * p.scale[n] + p.shift[n];
-        if (p.res) v += p.res[(size_t)m * p.ldres + n];
+        if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres + n];
         if (p.relu_out) v = fmaxf(v, 0.f);
         p.out[(size_t)m * p.ldout + n] = v;
     }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
     acc = wave_sum(acc);
     if (lane == 0) {
         float v = acc * p.scale[0] + p.shift[0];
-        if (p.res) v += p.res[(size_t)m * p.ldres];
+        if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres];
         if (p.relu_out) v = fmaxf(v, 0.f);
         p.out[(size_t)m * p.ldout] = v;
     }
@@ -301,7 +302,7 @@ __global__ void wino_input_kernel(const float* __restrict__ in, int ldin, int B,
 
 __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, int Wo, int Cout, int th, int tw,
                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                   const float* __restrict__ res, int ldres, int relu_out, float* __restrict__ out, int ldout) {
+                                   const float* __restrict__ res, int ldres, int res_bcast, int relu_out, float* __restrict__ out, int ldout) {
     const int N4 = Cout >> 2;
     const size_t P = (size_t)B * th * tw;
     const size_t total = P * N4;
@@ -338,7 +339,7 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
                 if (ow >= Wo) continue;
                 const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
                 f32x4 v = y[dy][dx] * sc + sh;
-                if (res) v += *reinterpret_cast<const f32x4*>(res + pix * ldres + n4 * 4);
+                if (res) v += *reinterpret_cast<const f32x4*>(res + (res_bcast ? (size_t)oh * Wo + ow : pix) * ldres + n4 * 4);
                 if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
             }
@@ -353,7 +354,7 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
 // loop than the per-position GEMMs.  A = V[xi][m][k] (from wino_input_kernel), B = U[xi][n][k] = (G g G^T).
 struct WinoArgs {
     const float* V; const float* U; const float* scale; const float* shift; const float* res; float* out;
-    int P, Cin, Cout, B, Ho, Wo, th, tw, ldout, ldres, relu_out, nk, tiles_m, tiles_n;
+    int P, Cin, Cout, B, Ho, Wo, th, tw, ldout, ldres, relu_out, nk, tiles_m, tiles_n, res_bcast;
 };
 
 template <int BM, int BN, int TM, int TN, int BK>
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(WinoArgs p) {
                     if (oh >= p.Ho || ow >= p.Wo) continue;
                     const size_t pix = ((size_t)b * p.Ho + oh) * p.Wo + ow;
                     float v = y[o][i][j][r] * sc + sh;
-                    if (p.res) v += p.res[pix * p.ldres + n];
+                    if (p.res) v += p.res[(p.res_bcast ? (size_t)oh * p.Wo + ow : pix) * p.ldres + n];
                     if (p.relu_out) v = fmaxf(v, 0.f);
                     p.out[pix * p.ldout + n] = v;
                 }
@@ -631,7 +632,7 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     a.relu_in = d->relu_in; a.relu_out = d->relu_out;
     a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
     a.tiles_m = pl.bm ? cdiv(a.M, pl.bm) : 0; a.tiles_n = pl.bn ? cdiv(a.Cout, pl.bn) : 0;
-    a.raw = 0; a.in_gstride = 0; a.w_gstride = 0; a.out_gstride = 0;
+    a.raw = 0; a.res_mod = d->res_broadcast ? Ho * Wo : 0; a.in_gstride = 0; a.w_gstride = 0; a.out_gstride = 0;
     if (pl.wino) {
         const int th = cdiv(Ho, 2), tw = cdiv(Wo, 2);
         const size_t P = (size_t)d->B * th * tw;
@@ -650,6 +651,7 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
             wa.V = V; wa.U = d->w_winograd; wa.scale = d->scale; wa.shift = d->shift; wa.res = d->res; wa.out = d->out;
             wa.P = (int)P; wa.Cin = d->Cin; wa.Cout = d->Cout; wa.B = d->B; wa.Ho = Ho; wa.Wo = Wo; wa.th = th; wa.tw = tw;
             wa.ldout = d->ldout; wa.ldres = d->ldres; wa.relu_out = d->relu_out; wa.nk = cdiv(d->Cin, 32);
+            wa.res_bcast = d->res_broadcast ? 1 : 0;
             const int bm = pl.fused == 1 ? 128 : 64, bn = pl.fused == 3 ? 128 : 64;
             wa.tiles_m = cdiv(wa.P, bm); wa.tiles_n = cdiv(wa.Cout, bn);
             const size_t lds = 2 * (size_t)(bm + bn) * 36 * sizeof(float);
@@ -672,7 +674,7 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         tot = P * (d->Cout / 4);
         blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(wino_output_kernel, dim3(blocks), dim3(256), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
-                           d->res, d->ldres, d->relu_out, d->out, d->ldout);
+                           d->res, d->ldres, d->res_broadcast ? 1 : 0, d->relu_out, d->out, d->ldout);
         return xmem_check_launch();
     }
     if (pl.splitk > 1) {

@@ -40,6 +40,7 @@ class XMem:
         # forked stream next to the small-grid layer2 / layer3 kernels.  Measured neutral on MI355X (A/B on one box:
         # 272 vs 273 fps), so it is off by default (XMEM_OVERLAP=1 enables it).
         self.overlap_skips = os.environ.get('XMEM_OVERLAP', '0') != '0'
+        self.share_x = os.environ.get('XMEM_SHARE_X', '1') != '0'     # several objects: convolve the shared f16 half of the fusers once
         self._side = None
         weights = self.init_hyperparameters(config, model_path, map_location)
         if weights is not None:
@@ -181,6 +182,20 @@ class XMem:
 
         fusion('value_encoder.fuser')
         fusion('decoder.fuser')
+
+        def split_shared(name, x_dim=1024):
+            """FeatureFusionBlock sees cat([x, g]) where x (the f16 feature) is the same for every object: W*cat = W[:, :x]*x +
+            W[:, x:]*g, so with several objects the x half is convolved once and enters the per-object half as a
+            broadcast residual (its scale is 1, the bias stays with the per-object half)."""
+            cw = W[name]
+            ones, zeros = torch.ones_like(cw.scale), torch.zeros_like(cw.shift)
+            W[name + '@x'] = ConvWeights(cw.w[..., :x_dim].contiguous(), ones, zeros, cw.stride, cw.pad)
+            W[name + '@g'] = ConvWeights(cw.w[..., x_dim:].contiguous(), cw.scale, cw.shift, cw.stride, cw.pad)
+
+        for blk in ('value_encoder.fuser.block1', 'decoder.fuser.block1'):
+            for c in ('.conv1', '.downsample'):
+                if (blk + c) in W and W[blk + c].cin > 1024 and (W[blk + c].cin - 1024) % 32 == 0:
+                    split_shared(blk + c)
         if self.hidden_dim > 0:
             W['value_encoder.hidden_reinforce.transform'] = self._conv_w('value_encoder.hidden_reinforce.transform', None, 1, 1)
             W['decoder.hidden_update.g16_conv'] = self._conv_w('decoder.hidden_update.g16_conv', None, 1, 0)
@@ -273,9 +288,28 @@ class XMem:
         res = ops.conv2d(g, W[p + '.downsample']) if (p + '.downsample') in W else g
         return ops.conv2d(o, W[p + '.conv2'], res=res, out=out, out_ld=out_ld)
 
-    def _fusion(self, cat, p):
-        """FeatureFusionBlock, model/modules.py:31-41, on the already concatenated [x | g] tensor."""
-        g = self._group_res(cat, p + '.block1')
+    def _shares_x(self, p, n_obj):
+        """True when `_fusion(cat, p, x)` convolves the shared x half once (several objects, split weights uploaded)."""
+        W = self._w
+        return n_obj > 1 and self.share_x and (p + '.block1.conv1@x') in W and (p + '.block1.downsample@x') in W
+
+    def _fusion(self, cat, p, x=None):
+        """FeatureFusionBlock, model/modules.py:31-41, on the already concatenated [x | g] tensor.  With several objects
+        and `x` given ([1,h,w,1024], the shared f16 half of `cat`), block1's two 3x3 convolutions run the x half once
+        and only the g half per object (saves 64 % / 80 % of block1's FLOPs for every object but the first)."""
+        W = self._w
+        b1 = p + '.block1'
+        if x is not None and self._shares_x(p, cat.shape[0]):
+            xd = x.shape[3]
+            gpart = cat[..., xd:]
+            ld, cg = cat.shape[3], cat.shape[3] - xd
+            sx = ops.conv2d(x, W[b1 + '.conv1@x'], relu_in=True)
+            o = ops.conv2d(gpart, W[b1 + '.conv1@g'], relu_in=True, relu_out=True, res=sx, res_broadcast=True, in_ld=ld, cin=cg)
+            dx = ops.conv2d(x, W[b1 + '.downsample@x'])
+            res = ops.conv2d(gpart, W[b1 + '.downsample@g'], res=dx, res_broadcast=True, in_ld=ld, cin=cg)
+            g = ops.conv2d(o, W[b1 + '.conv2'], res=res)
+        else:
+            g = self._group_res(cat, b1)
         g = ops.cbam_residual(g, self._cbam[p + '.attention'])
         return self._group_res(g, p + '.block2')
 
@@ -356,9 +390,10 @@ class XMem:
         g = self._stage(g, 'value_encoder.layer3', 2, self._basic)
         K, h, w, cg = g.shape
         cat = torch.empty((K, h, w, f16.shape[3] + cg), dtype=torch.float32, device=g.device)
-        ops.copy_channels(f16, cat, 0)
+        if not self._shares_x('value_encoder.fuser', K):
+            ops.copy_channels(f16, cat, 0)
         ops.copy_channels(g, cat, f16.shape[3])
-        value = self._fusion(cat, 'value_encoder.fuser')
+        value = self._fusion(cat, 'value_encoder.fuser', x=f16)
         if is_deep_update and self.hidden_dim > 0:
             cat2 = torch.empty((K, h, w, self.value_dim + self.hidden_dim), dtype=torch.float32, device=g.device)
             ops.copy_channels(value, cat2, 0)
@@ -399,10 +434,11 @@ class XMem:
         W = self._w
         K, h, w, _ = cat16.shape
         hd = self.hidden_dim
-        ops.copy_channels(f16, cat16, 0)
+        if not self._shares_x('decoder.fuser', K):
+            ops.copy_channels(f16, cat16, 0)               # with several objects the f16 half is convolved once (see _fusion)
         if hd > 0:
             ops.copy_channels(hidden, cat16, 1024 + self.value_dim)
-        g16 = self._fusion(cat16, 'decoder.fuser')
+        g16 = self._fusion(cat16, 'decoder.fuser', x=f16)
         skip8 = skips[0] if skips is not None else ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
         g8 = self._group_res(ops.upsample2x_add(g16, skip8), 'decoder.up_16_8.out_conv')
         skip4 = skips[1] if skips is not None else ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])

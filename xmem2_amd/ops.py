@@ -170,7 +170,8 @@ def _tune_conv(lib, d, x_device):
     return best
 
 
-def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None, plan=None):
+def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None, plan=None,
+           res_broadcast=False):
     """x [B,H,W,C] NHWC (or any buffer whose pixel stride is `in_ld`) -> out [B,Ho,Wo,Cout]."""
     lib = load()
     _req(x, 'conv2d input')
@@ -192,6 +193,7 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.scale = cw.scale.data_ptr(); d.shift = cw.shift.data_ptr()
     d.res = res.data_ptr() if res is not None else None
     d.ldres = res.shape[-1] if res is not None else 0
+    d.res_broadcast = int(bool(res_broadcast and res is not None))   # res [1,Ho,Wo,C] added to every batch element
     d.out = out.data_ptr(); d.ldout = out_ld
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     d.w_winograd = cw.wu.data_ptr() if cw.wu is not None else None
