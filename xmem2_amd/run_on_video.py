@@ -71,6 +71,7 @@ class VideoReader:
         masks = sorted(os.listdir(mask_dir))
         self.first_gt_path = os.path.join(mask_dir, masks[0])
         self.reference_mask = Image.open(self.first_gt_path).convert('P')
+        self.reference_mask.load()                   # decoded once here: the writer threads only read it afterwards
 
     def __len__(self):
         return len(self.frames)
