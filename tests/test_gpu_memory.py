@@ -8,6 +8,7 @@ import torch
 
 from conftest import load_golden
 from test_oracle_goldens import _feed, _query
+from oracle import cpu_ref as R
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -88,3 +89,30 @@ def test_clear_memory_keep_permanent(hip_net):
     assert core.memory.temporary_work_mem.size == 0 and core.memory.permanent_work_mem.size == 6 * 8
     p = core.step(fr[2], None, None)
     assert p.shape == (2, 96, 128) and bool(torch.isfinite(p).all())
+
+
+def test_read_memory_and_memory_util_dense_forms(hip_net):
+    """the training-time read (`XMem.read_memory`, full softmax + dense readout) and the
+    reference-shaped memory_util wrappers against the oracle."""
+    from xmem2_amd import memory_util as MU
+    g = torch.Generator().manual_seed(5)
+    B, K, CK, CV, T, h, w = 2, 2, 64, 512, 3, 6, 8
+    qk = torch.randn(B, CK, h, w, generator=g) * 0.8
+    qe = torch.rand(B, CK, h, w, generator=g)
+    mk = torch.randn(B, CK, T, h, w, generator=g) * 0.8
+    ms = torch.rand(B, 1, T, h, w, generator=g) * 2 + 1
+    mv = torch.randn(B, K, CV, T, h, w, generator=g)
+    sim_ref = R.get_similarity(mk, ms, qk, qe)
+    aff_ref = R.do_softmax(sim_ref)
+    want = torch.bmm(mv.flatten(1, 2).flatten(start_dim=2), aff_ref).view(B, K, CV, h, w)
+    got = hip_net.read_memory(qk.cuda(), qe.cuda(), mk.cuda(), ms.cuda(), mv.cuda())
+    assert got.shape == want.shape
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-4)
+    sim = MU.get_similarity(mk.cuda(), ms.cuda(), qk.cuda(), qe.cuda())
+    torch.testing.assert_close(sim.cpu(), sim_ref, rtol=1e-4, atol=1e-4)
+    sim2 = MU.get_similarity(mk.cuda(), None, qk.cuda(), None)
+    torch.testing.assert_close(sim2.cpu(), R.get_similarity(mk, None, qk, None), rtol=1e-4, atol=1e-4)
+    aff, usage = MU.do_softmax(sim, top_k=10, return_usage=True)
+    aff_r, usage_r = R.do_softmax(sim_ref.clone(), top_k=10, return_usage=True)
+    torch.testing.assert_close(aff.cpu(), aff_r, rtol=2e-3, atol=1e-6)
+    torch.testing.assert_close(usage.cpu(), usage_r, rtol=2e-3, atol=1e-6)

@@ -313,6 +313,17 @@ class XMem:
         g = ops.cbam_residual(g, self._cbam[p + '.attention'])
         return self._group_res(g, p + '.block2')
 
+    def read_memory(self, query_key, query_selection, memory_key, memory_shrinkage, memory_value):
+        """model/network.py:89-105 (training-time read: full softmax over all memory elements, dense readout).
+        query_* B x CK x H x W, memory_key B x CK x T x H x W, memory_shrinkage B x 1 x T x H x W,
+        memory_value B x num_objects x CV x T x H x W -> B x num_objects x CV x H x W."""
+        from .memory_util import get_affinity, readout
+        batch_size, num_objects = memory_value.shape[:2]
+        mv = memory_value.flatten(start_dim=1, end_dim=2)
+        affinity = get_affinity(memory_key, memory_shrinkage, query_key, query_selection)
+        memory = readout(affinity, mv)
+        return memory.view(batch_size, num_objects, self.value_dim, *memory.shape[-2:])
+
     # ---- hot path (NHWC) ------------------------------------------------------------------------
     def encode_key_nhwc(self, image4, need_sk=True, need_ek=True, with_skips=False, slot=0, inline_skips=False):
         """image4 [B,Hp,Wp,4] -> key [B*h*w,Ck], shrinkage [B*h*w]|None, selection|None, f16, f8, f4 (NHWC)
