@@ -159,3 +159,56 @@ def test_oracle_selector_properties():
     other = [(torch.rand(1, 64, 96, generator=g) > 0.3).float() for _ in range(F_)]
     a0 = R.select_next_candidates(keys, shr, sel, masks, 2, alpha=0.0)
     assert a0 == R.select_next_candidates(keys, shr, sel, other, 2, alpha=0.0)
+
+
+def test_harness_host_pieces(tmp_path):
+    """CPU-only pieces of the video harness: threaded decode prefetcher (order, pinned-or-not uint8 frames, lazy float
+    view = ToTensor + Normalize), multi-thread writer, ToTensor semantics of the mask reader."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    import xmem2_amd.run_on_video as rov
+    imgs, msks = tmp_path / 'JPEGImages', tmp_path / 'Annotations'
+    imgs.mkdir(); msks.mkdir()
+    rng = np.random.default_rng(0)
+    arrs = []
+    for i in range(9):
+        a = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8); arrs.append(a)
+        Image.fromarray(a).save(imgs / f'{i:04d}.png')
+    m = np.zeros((20, 30), np.uint8); m[5:12, 8:20] = 1
+    pm = Image.fromarray(m, mode='P'); pm.putpalette([0, 0, 0, 255, 0, 0] + [0] * 762); pm.save(msks / '0000.png')
+    reader = rov.VideoReader('', str(imgs), str(msks), size=-1, use_all_masks=True)
+    assert len(reader) == 9
+    orig_pin = torch.Tensor.pin_memory
+    try:
+        if not torch.cuda.is_available():                      # pinning needs a device runtime; the logic under test does not
+            torch.Tensor.pin_memory = lambda self, *a, **k: self
+        pf = rov.FramePrefetcher(reader, depth=4, workers=3)
+        got = pf.get(4) + pf.get(1) + pf.get(4)
+        pf.close()
+    finally:
+        torch.Tensor.pin_memory = orig_pin
+    assert [s.frame for s in got] == [f'{i:04d}.png' for i in range(9)]
+    for s, a in zip(got, arrs):
+        assert s.rgb_u8.dtype == torch.uint8 and np.array_equal(s.rgb_u8.numpy(), a)
+        want = ((a.astype(np.float32) / 255.0 - rov.IM_MEAN) / rov.IM_STD).transpose(2, 0, 1)
+        assert np.array_equal(s.rgb.numpy(), want) and s.rgb is s.rgb
+    assert got[0].mask is not None and got[1].mask is None and got[0].shape == (20, 30)
+    # writer threads: jobs run off-thread, files appear, errors surface at close()
+    saver = rov._AsyncSaver(str(tmp_path / 'out'), 'vid', max_queue=8, workers=3)
+    for i in range(6):
+        saver.submit(lambda i=i: [(Image.fromarray(arrs[i]), 'masks', f'{i}.png')])
+    saver.close()
+    assert sorted(p.name for p in (tmp_path / 'out' / 'vid' / 'masks').iterdir()) == [f'{i}.png' for i in range(6)]
+    bad = rov._AsyncSaver(str(tmp_path / 'out2'), '', workers=1)
+    bad.submit(lambda: (_ for _ in ()).throw(RuntimeError('boom')))
+    import pytest
+    with pytest.raises(RuntimeError):
+        bad.close()
+    # ToTensor semantics: palette index plane / 255, RGB planes / 255, bilevel -> {0, 1}
+    t = rov._pil_to_tensor01(Image.open(msks / '0000.png'))
+    assert t.shape == (1, 20, 30) and float(t.max()) == float(torch.tensor(1.0) / 255)
+    t = rov._pil_to_tensor01(Image.fromarray(arrs[0]))
+    assert t.shape == (3, 20, 30) and torch.equal(t, torch.from_numpy(arrs[0]).permute(2, 0, 1).float() / 255)
+    t = rov._pil_to_tensor01(Image.fromarray(m > 0))
+    assert t.shape == (1, 20, 30) and set(t.unique().tolist()) == {0.0, 1.0}
