@@ -13,6 +13,7 @@
 //
 // Replaces the nn.Conv2d/BatchNorm2d/ReLU/residual call sites listed in include/xmem_hip.h.
 #include "common.hpp"
+#include <stdlib.h>
 
 // BK (k-depth of a staged tile) is a template parameter: 32 or 64.  LDS rows are padded by 4 floats:
 // stride 36 (=9x16 B) or 68 (=17x16 B) floats; both are odd multiples of 16 B, so the 16 lanes of a ds_read_b128
@@ -33,7 +34,11 @@ struct ConvArgs {
     long in_gstride, w_gstride, out_gstride;   // blockIdx.y = group (the 16 Winograd tile positions), floats
 };
 
-template <int BM, int BN, int TM, int TN, int BK, bool GENERIC>
+// ONE: 1x1 / stride 1 / pad 0 with Cin % BK == 0 (the pointwise layers and the 16 Winograd-domain GEMMs): operand rows are
+// plain matrix rows, so each thread keeps loop-invariant 32-bit byte offsets and the K loop only advances a uniform base -
+// no per-tile index arithmetic, bounds tests or exec-masked branches around the loads (rows past M / Cout are clamped:
+// their products are never stored).  The address VALU work of the general loader was comparable to the MFMA issue time.
+template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WN = BN / (32 * TN);
     constexpr int WM = BM / (32 * TM);
@@ -81,10 +86,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     const int kt_begin = blockIdx.z * p.kt_per_split;
     const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
 
+    unsigned a_boff[RA], b_boff[RB];           // ONE: byte offsets of this thread's operand rows (k = 0)
+    if (ONE) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = min(m0 + lrow + RPP * i, p.M - 1);
+            a_boff[i] = ((unsigned)m * (unsigned)p.ldin + (unsigned)(c4 * 4)) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = min(n0 + lrow + RPP * i, p.Cout - 1);
+            b_boff[i] = ((unsigned)n * (unsigned)p.K + (unsigned)(c4 * 4)) * 4u;
+        }
+    }
+
     f32x4 ra[RA], rb[RB];
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (ONE) {
+            const char* abase = reinterpret_cast<const char*>(gin) + (size_t)k0 * 4;
+            const char* bbase = reinterpret_cast<const char*>(gw) + (size_t)k0 * 4;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + a_boff[i]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bbase + b_boff[i]);
+            return;
+        }
         if (!GENERIC) {
             const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
@@ -108,13 +136,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 ra[i] = ok ? *reinterpret_cast<const f32x4*>(gin + off) : zero;
             }
         }
-        if (p.relu_in) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
-                ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
-            }
-        }
         const int kb = k0 + c4 * 4;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -126,6 +147,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     auto store_tile = [&](int buf) {
         float* As = smem + buf * BUF;
         float* Bs = As + BM * LDK;
+        if (p.relu_in) {                       // relu-on-load, applied when the data is consumed (never right after the
+#pragma unroll                                 // global load: that would stall the wave before its MFMAs)
+            for (int i = 0; i < RA; ++i) {
+                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
+                ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * LDK + c4 * 4]) = ra[i];
 #pragma unroll
@@ -153,20 +181,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 
         const float* As = smem + buf * BUF + (wm * 32 * TM + l31) * LDK + lh * 4;
         const float* Bs = smem + buf * BUF + BM * LDK + (wn * 32 * TN + l31) * LDK + lh * 4;
+        // fragment loads run one k-group ahead of the MFMAs (two register sets): the ds_read latency of group kk+1 hides
+        // under the MFMA chain of group kk instead of stalling the wave between groups
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 af[TM], bf[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + kk * 8);
+                for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + (kk + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + kk * 8);
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + (kk + 1) * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch above this k-group's MFMAs
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
         }
         if (has_next) store_tile(buf ^ 1);
         __syncthreads();
@@ -585,10 +623,19 @@ Plan make_plan(const xmem_conv_desc* d) {
     return pl;
 }
 
+// the 1x1 fast path needs 32-bit byte offsets into both operands (per group)
+static bool conv_is_one(const ConvArgs& a) {
+    static const int off = getenv("XMEM_CONV_ONE") && getenv("XMEM_CONV_ONE")[0] == '0';
+    if (off) return false;
+    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo &&
+           (double)a.M * a.ldin * 4.0 < 4.0e9 && (double)a.Cout * a.K * 4.0 < 4.0e9;
+}
+
 template <int BM, int BN, int TM, int TN, int BK, bool G>
 int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G>;
+    const size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false>;
+    if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
