@@ -34,7 +34,7 @@ struct ConvArgs {
     long in_gstride, w_gstride, out_gstride;   // blockIdx.y = group (the 16 Winograd tile positions), floats
 };
 
-// ONE: 1x1 / stride 1 / pad 0 with Cin % BK == 0 (the pointwise layers and the 16 Winograd-domain GEMMs): operand rows are
+// ONE: 1x1 / pad 0 (any stride) with Cin % BK == 0 (the pointwise layers and the 16 Winograd-domain GEMMs): operand rows are
 // plain matrix rows, so each thread keeps loop-invariant 32-bit byte offsets and the K loop only advances a uniform base -
 // no per-tile index arithmetic, bounds tests or exec-masked branches around the loads (rows past M / Cout are clamped:
 // their products are never stored).  The address VALU work of the general loader was comparable to the MFMA issue time.
@@ -91,7 +91,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = min(m0 + lrow + RPP * i, p.M - 1);
-            a_boff[i] = ((unsigned)m * (unsigned)p.ldin + (unsigned)(c4 * 4)) * 4u;
+            unsigned pix = (unsigned)m;
+            if (p.stride != 1) {               // strided pointwise layer (ResNet downsample): input pixel of output pixel m
+                const int b = m / p.HoWo, rem = m - b * p.HoWo;
+                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                pix = (unsigned)((b * p.H + oh * p.stride) * p.W + ow * p.stride);
+            }
+            a_boff[i] = (pix * (unsigned)p.ldin + (unsigned)(c4 * 4)) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -210,30 +216,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         __syncthreads();
     }
 
-    // epilogue: lane owns output channel n (col) and 16 pixels (rows) per 32x32 tile
+    // epilogue: lane owns output channel n (col) and 16 pixels (rows) per 32x32 tile.  The store mode is uniform, so it is
+    // decided once and each 32x32 block runs straight-line code: all residual loads of a block are issued together
+    // (one memory round trip per block instead of one per element) before the fused scale / shift / add / relu and stores.
+    const int mode = p.raw ? 0 : (p.splitk > 1 ? 1 : (p.res ? 3 : 2));
+    float* const obase = (mode == 1) ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : gout;
+    const long ldo = (mode == 1) ? (long)p.Cout : (long)p.ldout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * 32 * TN + j * 32 + l31;
         if (n >= p.Cout) continue;
         float sc = 1.f, sh = 0.f;
-        if (p.splitk == 1 && !p.raw) { sc = p.scale[n]; sh = p.shift[n]; }
+        if (mode >= 2) { sc = p.scale[n]; sh = p.shift[n]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * 32 * TM + i * 32 + 4 * lh;          // this lane's rows: mb + (r & 3) + 8 * (r >> 2)
+            float* const orow = obase + (size_t)mb * ldo + n;
+            float rv[16];
+            if (mode == 3) {
+                int mr = p.res_mod ? mb % p.res_mod : mb;                 // broadcast residual: row index modulo one image
+                const bool wrap_ok = p.res_mod >= 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = (r & 3) + 8 * (r >> 2);
+                    int t = mr + o;
+                    if (p.res_mod) { if (wrap_ok) { if (t >= p.res_mod) t -= p.res_mod; } else t = (mb + o) % p.res_mod; }
+                    rv[r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= p.M) continue;
+                const int o = (r & 3) + 8 * (r >> 2);
+                if (mb + o >= p.M) continue;
                 float v = acc[i][j][r];
-                if (p.raw) {
-                    gout[(size_t)m * p.ldout + n] = v;
-                } else if (p.splitk == 1) {
+                if (mode >= 2) {
                     v = v * sc + sh;
-                    if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres + n];
+                    if (mode == 3) v += rv[r];
                     if (p.relu_out) v = fmaxf(v, 0.f);
-                    gout[(size_t)m * p.ldout + n] = v;
-                } else {
-                    p.partial[((size_t)blockIdx.z * p.M + m) * p.Cout + n] = v;
                 }
+                orow[(long)o * ldo] = v;
             }
         }
     }
@@ -627,8 +648,8 @@ Plan make_plan(const xmem_conv_desc* d) {
 static bool conv_is_one(const ConvArgs& a) {
     static const int off = getenv("XMEM_CONV_ONE") && getenv("XMEM_CONV_ONE")[0] == '0';
     if (off) return false;
-    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo &&
-           (double)a.M * a.ldin * 4.0 < 4.0e9 && (double)a.Cout * a.K * 4.0 < 4.0e9;
+    return a.KH == 1 && a.KW == 1 && a.pad == 0 &&
+           (double)a.B * a.H * a.W * a.ldin * 4.0 < 4.0e9 && (double)a.Cout * a.K * 4.0 < 4.0e9;
 }
 
 template <int BM, int BN, int TM, int TN, int BK, bool G>
