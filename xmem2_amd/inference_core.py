@@ -5,12 +5,26 @@ driving the HIP kernels.  ``step()``, ``put_to_permanent_memory()``, ``clear_mem
 reference's conventions (image ``3 x H x W`` float32 normalised, mask ``K x H x W``, prob ``(K+1) x H x W``).
 """
 import collections
+import functools
 
 import torch
 
 from . import ops
 from .memory_manager import MemoryManager
 from .tensor_util import pad_amounts
+
+
+def _on_network_device(fn):
+    """Run the method with the network's GPU as torch's current device: the kernels are launched on torch's CURRENT stream,
+    so a core whose network lives on cuda:1 must not enqueue on cuda:0's stream when the caller never called set_device."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = getattr(self.network, 'device', None)
+        if dev is None or dev.type != 'cuda' or torch.cuda.current_device() == (dev.index if dev.index is not None else torch.cuda.current_device()):
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 class InferenceCore:
@@ -86,6 +100,7 @@ class InferenceCore:
         e = selection.view(1, h, w, ck).permute(0, 3, 1, 2) if selection is not None else None
         return k, s, e
 
+    @_on_network_device
     def encode_frame_key(self, image):
         """inference_core.py:53-61."""
         image4, _, _ = self._pack(image)
@@ -97,6 +112,7 @@ class InferenceCore:
         the next `step()`."""
         return self.prefetch_keys([image])[0]
 
+    @_on_network_device
     def prefetch_keys(self, images):
         """Enqueue ONE batched key-encoder pass for the next `len(images)` frames on a side stream.
 
@@ -151,6 +167,7 @@ class InferenceCore:
         return devs
 
     # ---- the per-frame step ----------------------------------------------------------------------
+    @_on_network_device
     def step(self, image, mask=None, valid_labels=None, end=False, manually_curated_masks=False,
              disable_memory_updates=False, do_not_add_mask_to_memory=False, return_key_and_stuff=False):
         """inference_core.py:62-152.  image: 3*H*W, mask: num_objects*H*W or None -> prob (K+1)*H*W."""
@@ -252,6 +269,7 @@ class InferenceCore:
             e = self._pfq.popleft()
             torch.cuda.current_stream().wait_event(e['event'])
 
+    @_on_network_device
     def put_to_permanent_memory(self, image, mask, ti=None):
         """inference_core.py:154-179."""
         self._drop_prefetch()
