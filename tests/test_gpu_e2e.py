@@ -270,3 +270,38 @@ def test_e2e_large_frames_vs_oracle(hip_net, ref_net, hw, n_obj, perm, steps):
     iou = inter / max(uni, 1)
     print(f'{hw}: IoU {iou:.5f}, argmax mismatch {mism}/{steps * hw[0] * hw[1]}')
     assert iou >= 0.999 and mism / (steps * hw[0] * hw[1]) < 1e-4
+
+
+def test_run_on_video_with_augmented_permanent_memory(tmp_path, hip_net):
+    """augment_images_with_masks (run_on_video.py:231-242): each annotated frame enters the permanent memory 1 + 11 times
+    ('best_all'); the harness call runs end to end and the augmented frames are valid memory frames."""
+    from PIL import Image
+    from conftest import base_config
+    from xmem2_amd.augmentations import get_determenistic_augmentations
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.run_on_video import run_on_video, VideoReader
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    imgs, msks, out = tmp_path / 'JPEGImages', tmp_path / 'Annotations', tmp_path / 'out'
+    imgs.mkdir(); msks.mkdir()
+    t, hw = 5, (96, 128)
+    frames = synthetic_frames(t, *hw); masks = synthetic_masks(t, 1, *hw)
+    palette = [0, 0, 0, 255, 255, 255] + [0] * (256 * 3 - 6)
+    for i in range(t):
+        rgb = np.clip((frames[i].transpose(1, 2, 0) * 0.229 + 0.45) * 255, 0, 255).astype(np.uint8)
+        Image.fromarray(rgb).save(imgs / f'frame_{i:06d}.png')
+        im = Image.fromarray(masks[i, 0].astype(np.uint8), mode='P'); im.putpalette(palette); im.save(msks / f'frame_{i:06d}.png')
+    stats = run_on_video(str(imgs), str(msks), str(out), frames_with_masks=[0], print_progress=False,
+                         augment_images_with_masks=True, overwrite_config={'model': None, 'size': -1}, save_overlay=False)
+    assert len(stats) == t and len(os.listdir(out / 'masks')) == t
+    # the preload itself, step by step: 12 permanent frames of h*w elements for one annotation
+    reader = VideoReader('', str(imgs), str(msks), size=-1, use_all_masks=True)
+    smp = reader[0]
+    core = InferenceCore(hip_net, base_config())
+    core.set_all_labels([1])
+    msk = T(masks[0])
+    core.put_to_permanent_memory(smp.rgb_u8.cuda(), msk.cuda())
+    for img_aug, mask_aug in get_determenistic_augmentations((3,) + hw, msk, subset='best_all'):
+        core.put_to_permanent_memory(reader.frame_u8(img_aug(smp.raw_image_pil)).cuda(), mask_aug(msk).cuda())
+    assert core.memory.permanent_work_mem.size == 12 * (hw[0] // 16) * (hw[1] // 16)
+    p = core.step(T(frames[1]).cuda(), None, None)
+    assert bool(torch.isfinite(p).all()) and float((p.sum(0) - 1).abs().max()) < 1e-4

@@ -212,3 +212,41 @@ def test_harness_host_pieces(tmp_path):
     assert t.shape == (3, 20, 30) and torch.equal(t, torch.from_numpy(arrs[0]).permute(2, 0, 1).float() / 255)
     t = rov._pil_to_tensor01(Image.fromarray(m > 0))
     assert t.shape == (1, 20, 30) and set(t.unique().tolist()) == {0.0, 1.0}
+
+
+def test_deterministic_augmentations_host_side():
+    """SURVEY 8(f) rank 3 (restated torchvision semantics, unpinned): list contents / order per subset, identity cases,
+    PIL-branch vs tensor-branch geometry, brightness / posterize arithmetic, blur of a constant image."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from xmem2_amd.augmentations import get_determenistic_augmentations, affine_pil, affine_tensor, gaussian_blur_pil
+    rng = np.random.default_rng(1)
+    img = Image.fromarray(rng.integers(0, 256, (48, 64, 3), dtype=np.uint8))
+    mask = torch.zeros(2, 48, 64); mask[0, 12:36, 20:50] = 1; mask[1, 4:10, 4:12] = 1
+    names = lambda subset: [a.name for a, _ in get_determenistic_augmentations((3, 48, 64), mask, subset)]
+    assert names('best_all') == ['bright', 'dark', 'reduce_bits', 'sharp', 'blur', 'rotate_right', 'rotate_left', 'zoom_out',
+                                 'zoom_in', 'shear_right', 'shear_left']
+    assert names('best_3') == ['blur', 'zoom_in', 'shear_right'] and len(names('all')) == 13
+    assert get_determenistic_augmentations((3, 48, 64), mask, 'original_only') is None     # the reference returns None here
+    for ia, ma in get_determenistic_augmentations((3, 48, 64), mask, 'all'):
+        out, m = ia(img), ma(mask)
+        assert out.size == img.size and out.mode == 'RGB' and m.shape == mask.shape
+        assert set(m.unique().tolist()) <= {0.0, 1.0}                                      # nearest sampling keeps masks binary
+        if ma.name == 'identity':
+            assert m is mask
+    a = np.asarray(img).astype(np.int32)
+    augs = dict((x.name, x) for x, _ in get_determenistic_augmentations((3, 48, 64), mask, 'all'))
+    assert np.abs(np.asarray(augs['bright'](img)).astype(np.int32) - np.clip(a * 1.5, 0, 255)).max() <= 1
+    assert np.array_equal(np.asarray(augs['reduce_bits'](img)), np.asarray(img) & 0xE0)
+    g = np.asarray(augs['gray'](img)); assert np.array_equal(g[..., 0], g[..., 1]) and np.array_equal(g[..., 1], g[..., 2])
+    const = Image.fromarray(np.full((20, 30, 3), 77, np.uint8))
+    assert np.array_equal(np.asarray(gaussian_blur_pil(const, 7)), np.asarray(const))      # reflect padding, kernel sums to 1
+    assert torch.equal(affine_tensor(mask), mask) and np.array_equal(np.asarray(affine_pil(img)), np.asarray(img))
+    b = (mask[0].numpy() * 255).astype(np.uint8)
+    for kw in (dict(angle=30.0), dict(angle=-30.0), dict(scale=1.5), dict(shear=20), dict(shear=-20), dict(translate=(12, 0))):
+        p = np.asarray(affine_pil(Image.fromarray(b), **kw)) > 0
+        t = affine_tensor(mask[0:1], **kw)[0].numpy() > 0
+        assert (p != t).sum() <= 0.03 * t.sum(), kw                                         # same geometry in both backends
+    moved = affine_tensor(mask[0:1], translate=(12, 0))[0]
+    assert torch.equal(moved[:, 12:], mask[0][:, :-12]) and float(moved[:, :12].sum()) == 0

@@ -10,7 +10,7 @@ What is reproduced from the reference: config merge and the derived ``enable_lon
 (:190-196), preload of all annotated frames into permanent memory before the loop (:59-66), the per-frame
 ``step`` call and its flags (:98-108), resize + argmax post-processing (:165-173, on the GPU), the stats rows
 (:115-123) and the output layout ``<out>/masks/<frame>.png`` (+ ``overlay/<frame>.jpg``).
-Not reproduced: mp4 extraction (needs cv2), deterministic augmentations.
+Not reproduced: mp4 extraction (needs cv2).  `augment_images_with_masks` uses xmem2_amd/augmentations.py (unpinned restatement).
 """
 import collections
 import os
@@ -82,14 +82,21 @@ class VideoReader:
         s = self.size / min(h, w)                  # Resize(size): shorter side -> size
         return (self.size, int(w * s)) if h <= w else (int(h * s), self.size)
 
+    def frame_u8(self, img):
+        """PIL RGB image -> the working-size H x W x 3 uint8 tensor (the Resize of im_transform, video_reader.py:61-65;
+        ToTensor + Normalize happen on the device)."""
+        Image = self._Image
+        shape = (img.size[1], img.size[0])
+        th, tw = self._target_hw(*shape)
+        work = img if (th, tw) == shape else img.resize((tw, th), Image.BILINEAR)
+        return torch.from_numpy(np.array(work, dtype=np.uint8))                   # owns its memory
+
     def __getitem__(self, idx) -> Sample:
         Image = self._Image
         name = self.frames[idx]
         img = Image.open(os.path.join(self.image_dir, name)).convert('RGB')
         shape = (img.size[1], img.size[0])
-        th, tw = self._target_hw(*shape)
-        work = img if (th, tw) == shape else img.resize((tw, th), Image.BILINEAR)
-        rgb_u8 = torch.from_numpy(np.array(work, dtype=np.uint8))                 # H x W x 3, owns its memory
+        rgb_u8 = self.frame_u8(img)
         gt_path = os.path.join(self.mask_dir, name[:-4] + '.png')
         if not os.path.exists(gt_path):
             gt_path = os.path.join(self.mask_dir, name[:-4] + '.PNG')
@@ -271,8 +278,6 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
     from PIL import Image
     if not torch.cuda.is_available():
         raise RuntimeError('xmem2_amd.run_on_video needs an MI355X (HIP) device - there is no CPU path')
-    if augment_images_with_masks:
-        raise NotImplementedError('deterministic augmentations are not part of this tier (SURVEY.md 8f)')
     device = torch.device('cuda', torch.cuda.current_device())
     torch.autograd.set_grad_enabled(False)
     frames_with_masks = set(frames_with_masks)
@@ -301,6 +306,12 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
         torch.cuda.synchronize()
         preload_time += perf_counter() - a
         loaded = True
+        if augment_images_with_masks:                                # run_on_video.py:231-242, subset 'best_all'
+            from .augmentations import get_determenistic_augmentations
+            h, w = sample.rgb_u8.shape[:2]
+            for img_aug, mask_aug in get_determenistic_augmentations((3, h, w), msk, subset='best_all'):
+                rgb_aug = vid_reader.frame_u8(img_aug(sample.raw_image_pil))
+                processor.put_to_permanent_memory(rgb_aug.to(device), mask_aug(msk).to(device))
     if not loaded:
         raise ValueError('No valid masks provided!')
 
