@@ -460,28 +460,40 @@ __global__ void logits_to_prob_kernel(const float* __restrict__ logits, float* _
         int y0, y1, x0, x1; float ly, lx;
         bilinear_src(y, 0.25f, h4, y0, y1, ly);
         bilinear_src(x, 0.25f, w4, x0, x1, lx);
-        // pass 1: background product and max logit
+        // pass 1: background product and max logit.  The per-object logits are computed ONCE and kept in registers (first
+        // 8 objects): recomputing them per pass let the compiler contract the three copies differently, and a 1-ulp change
+        // of a saturated probability moves its logit by ~1e-4 - numerator and denominator must see the same value.
+        constexpr int KREG = 8;
+        float lbuf[KREG];
         float bgp = 1.f, mx = -INFINITY;
         for (int k = 0; k < K; ++k) {
             const float pk = sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx));
             bgp *= (1.f - pk);
-            mx = fmaxf(mx, agg_logit(pk));
+            const float lk = agg_logit(pk);
+            if (k < KREG) lbuf[k] = lk;
+            mx = fmaxf(mx, lk);
         }
         const float l0 = agg_logit(bgp);
         mx = fmaxf(mx, l0);
-        // pass 2: softmax denominator
-        float den = expf(l0 - mx);
+        auto logit_of = [&](int k) -> float {
+            if (k < KREG) return lbuf[k];
+            return agg_logit(sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx)));
+        };
+        // pass 2: softmax terms (kept for the first KREG objects) and denominator
+        float ebuf[KREG];
+        const float e0 = expf(l0 - mx);
+        float den = e0;
         for (int k = 0; k < K; ++k) {
-            const float pk = sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx));
-            den += expf(agg_logit(pk) - mx);
+            const float ek = expf(logit_of(k) - mx);
+            if (k < KREG) ebuf[k] = ek;
+            den += ek;
         }
         const int oy = y - lh, ox = x - lw;
         const bool inside = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
         // pass 3: write
         for (int k = -1; k < K; ++k) {
-            float l = l0;
-            if (k >= 0) l = agg_logit(sigmoidf_(bilinear4(logits + (size_t)k * h4 * w4, h4, w4, y0, y1, x0, x1, ly, lx)));
-            const float pr = expf(l - mx) / den;
+            const float ek = (k < 0) ? e0 : (k < KREG ? ebuf[k] : expf(logit_of(k) - mx));
+            const float pr = ek / den;
             if (inside) prob[((size_t)(k + 1) * H + oy) * W + ox] = pr;
             if (prob_pad) prob_pad[(size_t)(k + 1) * total + e] = pr;
         }

@@ -120,7 +120,7 @@ class InferenceCore:
         (the reference's DataLoader does, inference/run_on_video.py:80-92) can hint them: the pass runs in its own HIP
         graph and scratch while the current frames are still being read out / decoded on the main stream, and a batch
         of frames amortises the launch-bound 1/16-resolution layers (1.16 -> 0.82 ms per frame at batch 4).  `images`:
-        3 x H x W float32 tensors of one shape (pinned-CPU, or device tensors that are already complete).  Returns the
+        3 x H x W float32 (or decoded H x W x 3 uint8) tensors of one shape, pinned-CPU or device tensors that are complete.  Returns the
         device tensors to pass to the following `step()` calls IN ORDER; a `step()` on any other tensor simply drops
         the pending hints.  Not part of the reference surface: `step()` computes the same function without it."""
         net = self.network
