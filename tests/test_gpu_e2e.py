@@ -36,6 +36,7 @@ def _run_clip(hip_net, tag, hw, n_obj):
         p = core.step(frames[ti], mk, labels if mk is not None else None, end=(ti == t - 1),
                       do_not_add_mask_to_memory=(mk is not None))
         assert p.shape == (n_obj + 1,) + tuple(hw)
+        assert float((p.sum(0) - 1).abs().max()) < 5e-6, 'class probabilities must sum to one (softmax of the aggregated logits)'
         out.append(ops.argmax_u8(p).cpu().numpy())
         probs.append(p[:, 4::8, 4::8].cpu().numpy())
         m = core.memory
