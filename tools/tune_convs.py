@@ -10,7 +10,7 @@ import bench
 ops._plans = {} if os.environ.get('XMEM_RETUNE_ALL') else ops._load_plans()   # default: keep shipped plans, add new shapes
 net = XMem(dict(bench.b32_config()), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
 net.use_graphs = False
-for (H, W, K) in [(480, 854, 1), (480, 854, 2), (720, 1280, 1)]:
+for (H, W, K) in [(480, 854, 1), (480, 854, 2), (480, 854, 3), (720, 1280, 1), (240, 427, 1), (240, 427, 2), (1080, 1920, 1)]:
     cfg = bench.b32_config(); cfg['mem_every'] = 2
     fr = torch.from_numpy(synthetic_frames(4, H, W)).cuda(); mk = torch.from_numpy(synthetic_masks(4, K, H, W)).cuda()
     core = InferenceCore(net, cfg); core.set_all_labels(list(range(1, K + 1)))
