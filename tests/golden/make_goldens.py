@@ -165,6 +165,11 @@ def gen_memory():
                 key, shr, val, sel = _feed(None, step, kind, None, (h, w), n_obj)
                 for m in (ref, orc):
                     m.update_permanent_memory(ti, key.clone(), shr.clone(), val.clone(), selection=sel.clone())
+            elif kind == 'remove':
+                for m in (ref, orc):
+                    m.remove_from_permanent_memory(op[1])
+                assert ref.frame_id_to_permanent_mem_idx == orc.frame_id_to_permanent_mem_idx
+                rec[f'perm_index_{step}'] = np.array(sorted(ref.frame_id_to_permanent_mem_idx.items()), np.int64).reshape(-1, 2)
             elif kind == 'match':
                 qk = rnd((1, 64, h, w), 9000 + step * 10 + 1, 0.9)
                 qe = uni((1, 64, h, w), 9000 + step * 10 + 2, 0.05, 0.95)
@@ -208,6 +213,14 @@ def gen_memory():
     for _ in range(12):
         script_c += [('temp', [1]), ('match',)]
     run(script_c, cfg_c, 'lt_eviction')
+    # D: permanent-memory editing with TWO objects in the group: replace_at (value[gi] broadcast over the group's objects,
+    # kv_memory_store.py:100-118) and remove_from_permanent_memory (the saved frame POSITION is handed to remove_at as an
+    # element offset, memory_manager.py:204-210 -> kv_memory_store.py:120-123), incl. positions > 0
+    script_d = [('perm', [1, 2], 0), ('perm', [1, 2], 4), ('perm', [1, 2], 9), ('perm', [1, 2], 12), ('match',),
+                ('replace', 4, 2), ('match',), ('replace', 12, 2), ('match',),
+                ('remove', 9), ('match',), ('temp', [1, 2]), ('match',), ('remove', 0), ('match',),
+                ('perm', [1, 2], 20), ('match',), ('remove', 12), ('match',)]
+    run(script_d, cfg, 'perm_edit')
 
 
 # ----------------------------------------------------------------------------------------------
@@ -292,6 +305,73 @@ def gen_e2e(sd, ref_net):
 
 
 # ----------------------------------------------------------------------------------------------
+def gen_chair(sd, ref_net):
+    """BASELINE config 1: the first 10 frames of example_videos/chair (720x480, 1 object; PUMaVOS, CC BY 4.0 - copies under
+    tests/golden/chair/) driven through the imported reference's InferenceCore the way its harness does
+    (inference/run_on_video.py:59-66 preload, :94-137 frame loop, :165-173 post-process).  The harness module itself
+    cannot be imported here (torchvision / cv2 / progressbar are absent), so its few lines of glue are restated below:
+    decode = PIL, ToTensor + Normalize = the float32 formula of dataset/range_transform.py:5-8."""
+    print('chair clip (config 1): reference InferenceCore driven as run_on_video does')
+    from PIL import Image
+    from util.configuration import VIDEO_INFERENCE_CONFIG as REF_CFG
+    orc_net = R.RefNet(sd)
+    root = os.path.join(HERE, 'chair')
+    names = sorted(os.listdir(os.path.join(root, 'JPEGImages')))
+    mean = np.array([0.485, 0.456, 0.406], np.float32); std = np.array([0.229, 0.224, 0.225], np.float32)
+    rgbs, gts = [], []
+    for n in names:
+        u8 = np.array(Image.open(os.path.join(root, 'JPEGImages', n)).convert('RGB'), dtype=np.uint8)
+        x = torch.from_numpy(u8).permute(2, 0, 1).to(torch.float32).div(255)                  # ToTensor
+        x = (x - torch.from_numpy(mean)[:, None, None]) / torch.from_numpy(std)[:, None, None]   # Normalize
+        rgbs.append(x.contiguous())
+        gts.append(np.array(Image.open(os.path.join(root, 'Annotations', n[:-4] + '.png')).convert('P'), dtype=np.uint8))
+    t_all = len(names)
+
+    def run(tag, frames_with_masks, over):
+        cfg = dict(REF_CFG); cfg.update(over); cfg['model'] = None
+        cfg['enable_long_term_count_usage'] = bool(                                  # run_on_video.py:190-196
+            cfg['enable_long_term'] and
+            (t_all / (cfg['max_mid_term_frames'] - cfg['min_mid_term_frames']) * cfg['num_prototypes']) >= cfg['max_long_term_elements'])
+        ref, orc = HarnessCore(ref_net, cfg), R.RefCore(orc_net, cfg)
+        mapper = RefMapper()
+        for j in sorted(frames_with_masks):                                         # preload, :59-66 / :201-244
+            msk, _ = mapper.convert_mask(gts[j], exhaustive=True)
+            msk = torch.Tensor(msk)
+            for c in (ref, orc):
+                c.set_all_labels(list(mapper.remappings.values()))
+                c.put_to_permanent_memory(rgbs[j].clone(), msk.clone())
+        arg, pds, sizes, ious, provided = [], [], [], [], []
+        for ti in range(t_all):
+            msk = labels = None
+            if ti in frames_with_masks:
+                msk, labels = mapper.convert_mask(gts[ti], exhaustive=True)
+                msk = torch.Tensor(msk)
+                for c in (ref, orc):
+                    c.set_all_labels(list(mapper.remappings.values()))
+            kw = dict(end=(ti == t_all - 1), manually_curated_masks=False, do_not_add_mask_to_memory=(msk is not None))
+            p_ref = ref.step(rgbs[ti].clone(), msk.clone() if msk is not None else None, labels, **kw)
+            p_orc = orc.step(rgbs[ti].clone(), msk.clone() if msk is not None else None, labels, **kw)
+            beq(p_orc, p_ref, f'chair {tag} step {ti}')
+            assert not torch.isnan(p_ref).any()
+            out = torch.argmax(p_ref, dim=0).numpy().astype(np.uint8)                 # _post_process (no resize: 480 high)
+            arg.append(mapper.remap_index_mask(out))
+            pds.append(p_ref[:, 4::8, 4::8].numpy().copy())
+            provided.append(msk is not None)
+            ious.append(float(ref_tu.compute_array_iou(out, gts[ti])) if msk is None else -1.0)
+            m = ref.memory
+            sizes.append([m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size])
+        arg = np.stack(arg)
+        print(f'    chair {tag}: object fraction per frame {[(a > 0).mean().round(4) for a in arg]}')
+        print(f'    chair {tag}: IoU vs annotation {np.round(ious, 3)}; final sizes {sizes[-1]}')
+        save('chair_' + tag, argmax=arg, prob_ds8=np.stack(pds), sizes=np.array(sizes, np.int64), iou=np.array(ious),
+             mask_provided=np.array(provided), frames_with_masks=np.array(sorted(frames_with_masks)),
+             overwrite_config=np.array(repr(over)), names=np.array(names))
+
+    run('fm0', {0}, {})
+    run('fm0_5', {0, 5}, {'mem_every': 3})
+
+
+# ----------------------------------------------------------------------------------------------
 def gen_misc():
     print('misc: pad/unpad, aggregate, MaskMapper, IoU')
     x = rnd((3, 50, 70), 31)
@@ -318,6 +398,20 @@ def gen_misc():
 
 
 if __name__ == '__main__':
+    only = set(sys.argv[1:])                     # e.g. `make_goldens.py chair memory` regenerates a subset
+    if only:
+        if 'memory' in only:
+            gen_memory()
+        if only & {'chair', 'net', 'e2e'}:
+            sd = synthetic_state_dict(seed=0)
+            ref_net = build_ref_net(sd)
+            if 'net' in only:
+                gen_net(sd, ref_net)
+            if 'e2e' in only:
+                gen_e2e(sd, ref_net)
+            if 'chair' in only:
+                gen_chair(sd, ref_net)
+        sys.exit(0)
     gen_misc()
     gen_ops()
     gen_memory()
@@ -326,4 +420,5 @@ if __name__ == '__main__':
     ref_net = build_ref_net(sd)
     gen_net(sd, ref_net)
     gen_e2e(sd, ref_net)
+    gen_chair(sd, ref_net)
     print('all scenarios: oracle bit-equal to the imported reference; fixtures written to', HERE)

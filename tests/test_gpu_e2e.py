@@ -65,7 +65,7 @@ def test_e2e_clip(hip_net, tag, hw, n_obj):
     pr = g['prob_ds8']
     srt = np.sort(pr, axis=1)
     margin = srt[:, -1] - srt[:, -2]
-    clear = margin > 5e-2
+    clear = margin > 2e-2          # 2x the reference's own 8-vs-1-thread noise (1.1e-2)
     assert np.array_equal(probs.argmax(1)[clear], pr.argmax(1)[clear]), 'argmax differs where the reference margin is clear'
     assert d.mean() < 5e-4, f'mean prob error {d.mean():.3e}'
 

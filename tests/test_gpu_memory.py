@@ -18,15 +18,36 @@ def rows(t):            # [1,C,h,w] -> [hw, C] cuda
     return t[0].flatten(1).t().contiguous().cuda()
 
 
-@pytest.mark.parametrize('tag', ['single_group', 'two_groups', 'lt_eviction'])
+class _SimTap:
+    """Records the similarity matrices the oracle hands to its top-k softmax (one per object group and match call)."""
+
+    def __enter__(self):
+        self.sims, self._orig = [], R.do_softmax
+
+        def tap(similarity, *a, **kw):
+            self.sims.append(similarity.clone())
+            return self._orig(similarity, *a, **kw)
+        R.do_softmax = tap
+        return self
+
+    def __exit__(self, *exc):
+        R.do_softmax = self._orig
+
+
+@pytest.mark.parametrize('tag', ['single_group', 'two_groups', 'lt_eviction', 'perm_edit'])
 def test_memory_scripts_hip(tag):
+    """The HIP memory against the reference-recorded readouts.  A query may deviate from the recording only through a
+    top-k fork: its k-th and (k+1)-th similarities (taken from the oracle run next to it) are a near-tie, so the other
+    element may legitimately be picked.  Forks are budgeted at 0.5 % of the queries of a match and every one of them is
+    checked to BE such a near-tie; everything else must agree to fp32 round-off."""
     from xmem2_amd.memory_manager import MemoryManager
     g = load_golden('mem_' + tag)
     script = ast.literal_eval(str(g['script']))
     cfg = ast.literal_eval(str(g['config']))
     h, w = (int(x) for x in g['hw'])
-    mm = MemoryManager(cfg)
-    forked = False
+    mm, orc = MemoryManager(cfg), R.RefMemory(cfg)
+    k = cfg['top_k']
+    n_fork = n_q = 0
     for step, op in enumerate(script):
         if op[0] in ('perm', 'temp'):
             objects, ti = op[1], (op[2] if len(op) > 2 else None)
@@ -34,23 +55,37 @@ def test_memory_scripts_hip(tag):
             value = val[0].flatten(2).transpose(1, 2).contiguous().cuda()          # [K, HW, Cv]
             mm.add_memory(rows(key), shr.view(-1).cuda(), value, list(objects), selection=rows(sel),
                           permanent=(op[0] == 'perm'), ti=ti, hw_shape=(h, w))
+            orc.add_memory(key, shr, val, list(objects), selection=sel, permanent=(op[0] == 'perm'), ti=ti)
         elif op[0] == 'replace':
             key, shr, val, sel = _feed(step, op[2], (h, w))
             value = val[0].flatten(2).transpose(1, 2).contiguous().cuda()
             mm.update_permanent_memory(op[1], rows(key), shr.view(-1).cuda(), value, selection=rows(sel))
+            orc.update_permanent_memory(op[1], key, shr, val, selection=sel)
+        elif op[0] == 'remove':
+            mm.remove_from_permanent_memory(op[1])
+            orc.remove_from_permanent_memory(op[1])
+            assert sorted(mm.frame_id_to_permanent_mem_idx.items()) == [tuple(r) for r in g[f'perm_index_{step}'].tolist()]
         else:
             qk, qe = _query(step, (h, w))
             out = mm.match_memory(qk.cuda(), qe.cuda())
             torch.cuda.synchronize()
+            with _SimTap() as tap:
+                orc.match_memory(qk, qe)
             ref = T(g[f'readout_{step}'])
             err = (out.cpu() - ref).abs()
             scale = float(ref.abs().max())
-            # per query: a near-tie between the k-th and (k+1)-th similarity may legitimately pick the other element
-            # (its softmax weight is the smallest of the k); everything else must agree to fp32 round-off.
             per_q = err.amax(dim=(0, 1)).flatten()
             forked = per_q > 5e-5 * scale
-            assert float(forked.float().mean()) <= 0.03 and float(per_q.max()) < 0.1 * scale, \
+            n_fork += int(forked.sum()); n_q += forked.numel()
+            assert float(forked.float().mean()) <= 0.005 and float(per_q.max()) < 0.1 * scale, \
                 f'{tag} step {step}: {int(forked.sum())}/{forked.numel()} queries deviate, max err {float(per_q.max()):.3e} (scale {scale:.3e})'
+            for q in torch.nonzero(forked).flatten().tolist():       # every fork must be a k-th / (k+1)-th near-tie in some group
+                gaps = []
+                for sim in tap.sims:
+                    if sim.shape[1] > k:
+                        v = torch.topk(sim[0, :, q], k + 1).values
+                        gaps.append(float(v[k - 1] - v[k]) / max(1.0, abs(float(v[k - 1]))))
+                assert gaps and min(gaps) <= 2e-5, f'{tag} step {step} query {q}: deviates without a top-k near-tie (gaps {gaps})'
             if f'tmp_use_{step}' in g.files and mm.temporary_work_mem.size > 0:
                 u = mm.temporary_work_mem.use_count.cpu().numpy()
                 if u.shape == g[f'tmp_use_{step}'].shape:
@@ -63,6 +98,7 @@ def test_memory_scripts_hip(tag):
         for si, st in enumerate((mm.temporary_work_mem, mm.permanent_work_mem, mm.long_mem)):
             for gi in range(2):
                 assert (st.get_v_size(gi) if gi < st.num_groups else -1) == int(vs[si, gi])
+    print(f'{tag}: {n_fork} forked queries of {n_q}')
     if 'lt_key' in g.files and tag != 'lt_eviction':
         # prototypes themselves: same keys (exact gather) when the usage ranking did not fork
         lk = mm.long_mem.key.cpu()

@@ -73,7 +73,7 @@ def _query(step, hw):
     return qk, qe
 
 
-@pytest.mark.parametrize('tag', ['single_group', 'two_groups', 'lt_eviction'])
+@pytest.mark.parametrize('tag', ['single_group', 'two_groups', 'lt_eviction', 'perm_edit'])
 def test_memory_scripts(tag):
     g = load_golden('mem_' + tag)
     script = ast.literal_eval(str(g['script']))
@@ -88,6 +88,9 @@ def test_memory_scripts(tag):
         elif op[0] == 'replace':
             key, shr, val, sel = _feed(step, op[2], hw)
             mm.update_permanent_memory(op[1], key, shr, val, selection=sel)
+        elif op[0] == 'remove':
+            mm.remove_from_permanent_memory(op[1])
+            assert sorted(mm.frame_id_to_permanent_mem_idx.items()) == [tuple(r) for r in g[f'perm_index_{step}'].tolist()]
         else:
             qk, qe = _query(step, hw)
             r = mm.match_memory(qk, qe)

@@ -50,7 +50,7 @@ class XMem:
     def init_hyperparameters(self, config, model_path=None, map_location=None):
         """model/network.py:134-182: C_k/C_v/C_h from the checkpoint if given, else config/defaults; writes them back."""
         if model_path is not None:
-            weights = torch.load(model_path, map_location=map_location or 'cpu')
+            weights = torch.load(model_path, map_location=map_location or 'cpu', weights_only=True)
             self.key_dim, self.value_dim, self.hidden_dim = infer_dims(weights)
             self.disable_hidden = self.hidden_dim == 0
         else:
