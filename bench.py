@@ -1,16 +1,34 @@
 #!/usr/bin/env python
 """Benchmark of the per-frame memory-readout path (BASELINE.json: frames/sec at 480p, 1 object, 32 memory frames).
 
-Workload B32: synthetic 480x854 clip (pads to 480x864, HW=1620), 1 object, 32 annotated frames preloaded
-with put_to_permanent_memory, mem_every=1e9 so N stays 32*1620 = 51840; every timed step is
-encode_key -> match_memory -> segment -> resize/argmax -> uint8 mask on the host (run_on_video.py:106-113 timing;
-the device->host copy of frame t is awaited after frame t+1 is enqueued, every mask is on the host before the clock stops).
-One process per GPU; ranks run independent replica streams (no data-path collective); rank 0 prints ONE JSON line.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload b32|b32dyn|c3|c4|c5]
+
+Workloads (`--workload`, default b32 = BASELINE configs[1], the one the metric is quoted on):
+  b32     480x854, 1 object, 32 annotated frames preloaded with put_to_permanent_memory, mem_every=1e9: N stays 32*1620
+  b32dyn  480x854, 1 object, 22 permanent frames + mem_every=10, T_max=10, T_min=5, long-term on: encode_value and
+          consolidation inside the timed loop
+  c3      480x854, 3 objects, 1 permanent frame, mem_every=5 (DAVIS-like multi-object stream, consolidation)
+  c4      720x1280, 1 object, 256 permanent frames (N = 921 600) + long-term on
+  c5      1080x1920, 5 objects, 512 permanent frames (N = 4 177 920)
+Every timed step is step() (encode_key -> match_memory -> segment [-> encode_value -> add_memory]) -> resize/argmax ->
+uint8 mask on the host (run_on_video.py:106-113 timing; the device->host copy of frame t is awaited after frame t+1 is
+enqueued, every mask is on the host before the clock stops).
+
+N > 1: one process per GPU, independent replica streams, no data-path collective; `--gpus N` without a torchrun
+environment spawns the N ranks itself (xmem2_amd.launch.spawn_ranks) and refuses to run on fewer devices.  Rank 0 prints
+ONE JSON line.  Kernel-level numbers come from (i) HIP events on the launch stream around the eager memory-readout calls
+inside a second, instrumented pass of the timed schedule and (ii) a rocprofv3 --kernel-trace of this same command run as
+a child process and cut to the timed region with marker kernels (N=1, rank 0).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -21,19 +39,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from xmem2_amd.launch import shard_videos, spawn_ranks          # noqa: E402,F401  (shard_videos re-exported for callers)
+
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-H, W, MEM_FRAMES, CK, CV, TOPK = 480, 854, 32, 64, 512, 30
+CK, CV, TOPK = 64, 512, 30
+BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
+
+WORKLOADS = {
+    'b32': dict(H=480, W=854, K=1, perm=32, mem_every=10 ** 9, count_usage=False, n_query=32,
+                desc='B32: synthetic 480x854 clip, 1 object, 32 permanent memory frames (N=51840), mem_every=1e9'),
+    'b32dyn': dict(H=480, W=854, K=1, perm=22, mem_every=10, count_usage=True, n_query=32,
+                   desc='B32-dyn: 480x854, 1 object, 22 permanent frames + mem_every=10 (T_max=10, T_min=5, long-term on): '
+                        'encode_value + consolidation inside the timed loop'),
+    'c3': dict(H=480, W=854, K=3, perm=1, mem_every=5, count_usage=True, n_query=32,
+               desc='C3 stream: 480x854, 3 objects, 1 permanent frame, mem_every=5, long-term consolidation'),
+    'c4': dict(H=720, W=1280, K=1, perm=256, mem_every=10, count_usage=True, n_query=16,
+               desc='C4: 720x1280, 1 object, 256 permanent frames (N=921600) + long-term on, mem_every=10'),
+    'c5': dict(H=1080, W=1920, K=5, perm=512, mem_every=10 ** 9, count_usage=False, n_query=16,
+               desc='C5: 1080x1920 (pads to 1088), 5 objects, 512 permanent frames (N=4177920)'),
+}
 
 
 # ---- multi-rank helpers (covered by tests/test_multi_gpu.py with gloo) ------------------------------------
-def shard_videos(videos, lengths, rank, world):
-    """Longest-first, dealt round-robin: independent per-GPU streams, no exchange step."""
-    order = sorted(range(len(videos)), key=lambda i: -lengths[i])
-    return [videos[i] for i in order[rank::world]]
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def _reduce(value, device, op):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return value
     if dist.get_backend() != 'nccl':
         device = torch.device('cpu')
@@ -51,62 +84,93 @@ def sum_over_ranks(value, device):
     return int(round(v)) if isinstance(value, int) else v
 
 
+def gather_over_ranks(value, device):
+    """[value of rank 0, ..., value of rank N-1] on every rank."""
+    if not _active():
+        return [float(value)]
+    if dist.get_backend() != 'nccl':
+        device = torch.device('cpu')
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
 def barrier(device):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier(device_ids=[device.index] if (device.type == 'cuda' and dist.get_backend() == 'nccl') else None)
 
 
 # ---- workload ------------------------------------------------------------------------------------------------
+def workload_config(wl):
+    return dict(mem_every=wl['mem_every'], deep_update_every=-1, enable_long_term=True,
+                enable_long_term_count_usage=wl['count_usage'], hidden_dim=64, key_dim=CK, value_dim=CV, top_k=TOPK,
+                max_mid_term_frames=10, min_mid_term_frames=5, num_prototypes=128, max_long_term_elements=10000)
+
+
 def b32_config():
-    return dict(mem_every=10 ** 9, deep_update_every=-1, enable_long_term=True, enable_long_term_count_usage=False,
-                hidden_dim=64, key_dim=CK, value_dim=CV, top_k=TOPK, max_mid_term_frames=10, min_mid_term_frames=5,
-                num_prototypes=128, max_long_term_elements=10000)
+    return workload_config(WORKLOADS['b32'])
 
 
-def make_clip(n_query):
-    from xmem2_amd.synth import synthetic_frames, synthetic_masks
-    t = MEM_FRAMES + n_query
-    return synthetic_frames(t, H, W), synthetic_masks(t, 1, H, W)
+def padded(x):
+    return (x + 15) // 16 * 16
 
 
-def algorithmic_gflop_per_frame():
-    """F_key + F_dec(K=1) conv FLOPs + similarity; the readout runs in its sparse form."""
-    hp, wp = 480, 864
+def algorithmic_gflop_per_frame(wl, n_mem_elements=None):
+    """F_key + F_dec(K) conv FLOPs (+ F_val on memory frames) + similarity; the readout runs sparse."""
+    hp, wp, K = padded(wl['H']), padded(wl['W']), wl['K']
     hw = (hp // 16) * (wp // 16)
-    n = MEM_FRAMES * hw
+    n = n_mem_elements if n_mem_elements is not None else wl['perm'] * hw
     f_key = 139944 * hp * wp
-    f_dec = (147456 + 416779) * hp * wp
+    f_dec = (147456 + 416779 * K) * hp * wp
+    f_val = 214281 * K * hp * wp / wl['mem_every'] if wl['mem_every'] < 10 ** 8 else 0.0
     f_sim = 4 * CK * n * hw
-    f_ro = 2 * CV * TOPK * hw
-    return dict(key=f_key / 1e9, decoder=f_dec / 1e9, similarity=f_sim / 1e9, readout_sparse=f_ro / 1e9,
-                total=(f_key + f_dec + f_sim + f_ro) / 1e9)
+    f_ro = 2 * CV * TOPK * hw * K
+    return dict(key=f_key / 1e9, decoder=f_dec / 1e9, value_amortised=f_val / 1e9, similarity=f_sim / 1e9,
+                readout_sparse=f_ro / 1e9, conv=(f_key + f_dec + f_val) / 1e9,
+                total=(f_key + f_dec + f_val + f_sim + f_ro) / 1e9, memory_elements=n, hw=hw)
+
+
+def make_clip(wl):
+    """(frames [T,3,H,W], masks [T,K,H,W], perm(j) -> (frame, mask), n_query).  More than 32 permanent frames are 8 base
+    frames shifted by distinct offsets (distinct keys without generating hundreds of 1080p fields on the host)."""
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    H, W, K, P, nq = wl['H'], wl['W'], wl['K'], wl['perm'], wl['n_query']
+    base = P if P <= 32 else 8
+    frames = synthetic_frames(base + nq, H, W)
+    masks = synthetic_masks(base + nq, K, H, W)
+    return frames, masks, base, nq
 
 
 def run_gpu(args, device, rank, world):
     from xmem2_amd import InferenceCore, XMem, ops
+    from xmem2_amd.run_on_video import AsyncMaskFetcher
     from xmem2_amd.synth import synthetic_state_dict
-    cfg = b32_config()
+    wl = WORKLOADS[args.workload]
+    cfg = workload_config(wl)
     sd = synthetic_state_dict(0)
     net = XMem(dict(cfg), None).to(device).eval()
     net.load_weights(sd)
-    n_query = 32
-    frames, masks = make_clip(n_query)
+    frames, masks, base, n_query = make_clip(wl)
     fr = torch.from_numpy(frames).to(device)
     mk = torch.from_numpy(masks).to(device)
     core = InferenceCore(net, cfg)
-    core.set_all_labels([1])
+    core.set_all_labels(list(range(1, wl['K'] + 1)))
     t0 = time.perf_counter()
-    for j in range(MEM_FRAMES):
-        core.put_to_permanent_memory(fr[j], mk[j])
+    for j in range(wl['perm']):
+        if wl['perm'] <= 32:
+            core.put_to_permanent_memory(fr[j], mk[j])
+        else:
+            sh = (3 * (j // base), 5 * (j // base))
+            core.put_to_permanent_memory(torch.roll(fr[j % base], sh, (1, 2)), torch.roll(mk[j % base], sh, (1, 2)), ti=j)
     torch.cuda.synchronize(device)
     preload_s = time.perf_counter() - t0
-    assert core.memory.permanent_work_mem.size == MEM_FRAMES * 1620
+    hw = (padded(wl['H']) // 16) * (padded(wl['W']) // 16)
+    assert core.memory.permanent_work_mem.size == wl['perm'] * hw
 
-    from xmem2_amd.run_on_video import AsyncMaskFetcher
     fetcher = AsyncMaskFetcher()                      # uint8 masks reach the host one frame behind the GPU (as run_on_video)
-
     KB = max(1, args.key_batch)
-    frame = lambda i: fr[MEM_FRAMES + (i % n_query)]
+    frame = lambda i: fr[base + (i % n_query)]
 
     def hint(first):                                 # batched key encoder of frames [first, first+KB) on the side stream
         if not args.no_prefetch:
@@ -118,113 +182,275 @@ def run_gpu(args, device, rank, world):
             hint(i + KB)
         return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
 
-    # setup (untimed, like the preload): two batches of frames capture every HIP graph variant the stream will replay
-    hint(-2 * KB)
-    for i in range(-2 * KB, 0):
+    # setup (untimed, like the preload): enough frames to capture every HIP graph variant the stream will replay
+    # (two key batches; for dynamic memories two memory frames -> value-encoder graphs, deep-update variants)
+    me = wl['mem_every'] if wl['mem_every'] < 10 ** 8 else 0
+    setup = (2 * KB + 2 * me + KB - 1) // KB * KB
+    hint(-setup)
+    for i in range(-setup, 0):
         one_step(i)
     for i in range(args.warmup):
         one_step(i)
     fetcher.drain()
     # ---- timed region: exactly `steps` frames, barrier + device sync on both sides --------------------------
     barrier(device); torch.cuda.synchronize(device)
+    if args.traced_child:
+        ops.trace_marker(1)
     t0 = time.perf_counter()
     out_masks = []
     for i in range(args.steps):
         out_masks += one_step(args.warmup + i)
     out_masks += [m for _, m in fetcher.drain()]      # every mask of the timed steps is on the host before the clock stops
     assert len(out_masks) == args.steps
+    if args.traced_child:
+        ops.trace_marker(2)
     torch.cuda.synchronize(device); barrier(device)
     elapsed = time.perf_counter() - t0
-    # ---- per-kernel durations, measured live with HIP events on the launch stream: the launches of ONE frame are
-    # recorded in an eager pass (the timed region replays captured HIP graphs, which cannot carry timing events) and
-    # every distinct launch is then timed back to back (10 repetitions between two events).  profiles/ holds the
-    # rocprofv3 kernel trace of the timed command itself.
-    prof, prof_frames = {}, 0
-    if rank == 0:
-        core.cancel_prefetch()                           # the surveyed frame runs its own key encoder
-        ops.RECORD = []
-        one_step(args.warmup + args.steps)
+    m = core.memory
+    n_elems = m.temporary_work_mem.size + m.permanent_work_mem.size + m.long_mem.size
+    # ---- instrumented pass (rank 0): the SAME schedule again (graphs, two streams, batched hints) with HIP events on
+    # the launch stream around the memory-readout calls, which are eager launches between the captured stages
+    taps, inst_frames, inst_elapsed = {}, 0, None
+    if rank == 0 and not args.traced_child:
+        inst_frames = min(args.steps, 100)
+        ops.EVENT_TAP = []
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        start = args.warmup + args.steps
+        for i in range(inst_frames):
+            one_step(start + i)
         fetcher.drain()
-        records, ops.RECORD = ops.RECORD, None
-        prof = ops.time_recorded(records, reps=10)
-        prof_frames = 1
-    return dict(elapsed=elapsed, preload_s=preload_s, prof=prof, prof_frames=prof_frames, masks=out_masks, core=core,
-                frames=frames, masks_in=masks, sd=sd, n_query=n_query)
+        torch.cuda.synchronize(device)
+        inst_elapsed = time.perf_counter() - t1
+        events, ops.EVENT_TAP = ops.EVENT_TAP, None
+        for kind, e0, e1, flop in events:
+            d = taps.setdefault(kind, dict(ms=0.0, flop=0.0, calls=0))
+            d['ms'] += e0.elapsed_time(e1); d['flop'] += flop; d['calls'] += 1
+    core.cancel_prefetch()
+    return dict(elapsed=elapsed, preload_s=preload_s, taps=taps, inst_frames=inst_frames, inst_elapsed=inst_elapsed,
+                masks=out_masks, core=core, frames=frames, masks_in=masks, sd=sd, n_query=n_query, base=base,
+                n_elems=n_elems, wl=wl, cfg=cfg)
 
 
+# ---- rocprofv3 kernel trace of the timed region (child process) ------------------------------------------------
+FAMILIES = (('conv', ('conv_', 'wino_')),
+            ('affinity', ('affinity_',)),
+            ('readout', ('readout_sparse_kernel',)),
+            ('usage', ('usage_',)),
+            ('consolidation', ('topk_1d', 'gather_rows', 'similarity_dense', 'softmax_rows', 'weighted_rows', 'select_greater',
+                               'usage_ratio', 'consolid')),
+            ('cbam', ('cbam_',)))
+
+
+def family_of(name):
+    n = name[5:] if name.startswith('void ') else name
+    for fam, prefixes in FAMILIES:
+        if n.startswith(prefixes):
+            return fam
+    if n.startswith(('at::', '__amd_rocclr', 'rocclr', 'Cijk_')):
+        return 'torch_runtime'
+    return 'elementwise'
+
+
+def parse_kernel_trace(path):
+    """Rows of a rocprofv3 kernel-trace CSV between the two `xmem_trace_marker_kernel` launches -> per-kernel and
+    per-family table (launches, total ns) + wall ns of the window + union-busy ns."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].strip()))
+    rows.sort()
+    marks = [r for r in rows if r[2].startswith('xmem_trace_marker_kernel')]
+    if len(marks) < 2:
+        raise RuntimeError('trace markers not found in the kernel trace')
+    t0, t1 = marks[0][1], marks[-1][0]
+    sel = [r for r in rows if t0 <= r[0] < t1 and not r[2].startswith('xmem_trace_marker_kernel')]
+    kern, fam = {}, {}
+    busy, last = 0, t0
+    for s, e, name in sel:
+        k = kern.setdefault(name, [0, 0]); k[0] += 1; k[1] += e - s
+        g = fam.setdefault(family_of(name), [0, 0]); g[0] += 1; g[1] += e - s
+        a = max(s, last)
+        if e > a:
+            busy += e - a; last = e
+    return dict(window_ns=t1 - t0, busy_ns=busy, kernels=kern, families=fam, launches=len(sel))
+
+
+def run_traced_child(args):
+    """rocprofv3 --kernel-trace around a child copy of this command (fewer steps), cut to its timed region."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    steps = min(args.steps, args.trace_steps)
+    tmp = tempfile.mkdtemp(prefix='xmem_trace_', dir=os.environ.get('TMPDIR', '/tmp'))
+    cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', tmp, '--', sys.executable, os.path.abspath(__file__),
+           '--steps', str(steps), '--warmup', str(args.warmup), '--workload', args.workload, '--key-batch', str(args.key_batch),
+           '--traced-child', '--no-cpu-baseline']
+    if args.no_prefetch:
+        cmd.append('--no-prefetch')
+    env = dict(os.environ, TMPDIR=os.environ.get('TMPDIR', '/tmp'))
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    try:
+        p = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.trace_timeout)
+        files = glob.glob(os.path.join(tmp, '**', '*kernel_trace.csv'), recursive=True)
+        if p.returncode != 0 or not files:
+            return None, f'traced child failed (rc {p.returncode}): {p.stderr[-400:]}'
+        tr = parse_kernel_trace(max(files, key=os.path.getsize))
+        tr['steps'] = steps
+        if args.keep_trace:
+            os.makedirs(args.keep_trace, exist_ok=True)
+            shutil.copy(max(files, key=os.path.getsize), os.path.join(args.keep_trace, f'{args.workload}_kernel_trace.csv'))
+        return tr, None
+    except Exception as e:                                     # the headline number never depends on the tracer
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def committed_pmc(workload):
+    """HBM-side bytes per frame from the committed PMC passes (profiles/r*_pmc_per_frame*.json), quoted ONLY when they
+    were recorded for exactly this build of the kernels (source digest match) - otherwise None, never a stale number."""
+    from xmem2_amd.build import source_digest
+    dig = source_digest()
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*pmc_per_frame*.json'))):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except Exception:
+            continue
+        if j.get('source_digest') == dig and j.get('workload', 'b32') == workload:
+            best = (path, j)
+    if best is None:
+        return None
+    path, j = best
+    fam = {k: v['read_bytes'] + v['write_bytes'] for k, v in j['families'].items()}
+    return dict(file=os.path.relpath(path, ROOT), families=fam, mfma_busy=j.get('mfma_busy'))
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------------------------
 def run_cpu_baseline(res, args, device):
-    """The oracle (CPU restatement, bit-equal to the imported reference in the build container) on the same B32
-    workload, bounded sample: preload 32 frames (untimed), 1 warm-up + `cpu_frames` timed frames, all host threads.
-    Parity: a FRESH GPU stream (same preload, same frame order from the same start) is compared frame by frame."""
+    """The oracle (CPU restatement, bit-equal to the imported reference in the build container) on the same workload on
+    this box's host cores.  Protocol (bounded to keep the default run within minutes): thread sweep
+    {1, 8, 32, all} with 1 warm-up + 3 timed frames each, then 3 warm-up + `cpu_frames` (>= 20) timed frames at the best
+    thread count; medians.  Parity: a FRESH GPU stream (same preload, same frame order) is compared frame by frame."""
     from oracle import cpu_ref as R
     from xmem2_amd import InferenceCore, ops
-    cfg = b32_config()
+    wl, cfg = res['wl'], res['cfg']
     ref = R.RefCore(R.RefNet(res['sd']), cfg)
-    ref.set_all_labels([1])
-    fr, mk = res['frames'], res['masks_in']
+    labels = list(range(1, wl['K'] + 1))
+    ref.set_all_labels(labels)
+    fr, mk, base = res['frames'], res['masks_in'], res['base']
     gpu = InferenceCore(res['core'].network, cfg)
-    gpu.set_all_labels([1])
-    for j in range(MEM_FRAMES):
+    gpu.set_all_labels(labels)
+    all_threads = torch.get_num_threads()
+    torch.set_num_threads(min(all_threads, 32))
+    for j in range(wl['perm']):
         ref.put_to_permanent_memory(torch.from_numpy(fr[j]), torch.from_numpy(mk[j]))
         gpu.put_to_permanent_memory(torch.from_numpy(fr[j]).to(device), torch.from_numpy(mk[j]).to(device))
-    # GPU stream first, driven exactly like the timed region (batched key-encoder hints when enabled)
-    n = args.cpu_frames + 1
+    sweep = sorted({t for t in (1, 8, 32, all_threads) if t <= all_threads})
+    plan = [(t, 1, 3) for t in sweep]
+    n_total = sum(w + k for _, w, k in plan) + 3 + args.cpu_frames
     KB = max(1, args.key_batch)
-    idx_of = lambda i: MEM_FRAMES + (i % res['n_query'])
-    dev = [torch.from_numpy(fr[idx_of(i)]).to(device) for i in range(n + 2 * KB)]
+    idx_of = lambda i: base + (i % res['n_query'])
+    # GPU stream first, driven exactly like the timed region (batched key-encoder hints when enabled)
+    dev = [torch.from_numpy(fr[idx_of(i)]).to(device) for i in range(n_total + 2 * KB)]
     hint = (lambda a: gpu.prefetch_keys(dev[a:a + KB])) if not args.no_prefetch else (lambda a: None)
     hint(0)
     gpu_out = []
-    for i in range(n):
+    for i in range(n_total):
         pg = gpu.step(dev[i], None, None)
         if i % KB == 0:
             hint(i + KB)
-        gpu_out.append((ops.argmax_u8(pg).cpu().numpy(), pg.cpu()))
+        gpu_out.append((ops.argmax_u8(pg).cpu().numpy(), pg[:, 4::8, 4::8].cpu()))
     gpu.cancel_prefetch()
-    ious, mism, perr, times = [], 0, 0.0, []
-    for i in range(n):
-        t0 = time.perf_counter()
-        p = ref.step(torch.from_numpy(fr[idx_of(i)]), None, None)
-        m = R.post_process(p)
-        dt = time.perf_counter() - t0
-        if i >= 1:
-            times.append(dt)
-        g, pg = gpu_out[i]
-        ious.append(R.compute_array_iou(g, m))
-        mism += int((g != m).sum())
-        perr = max(perr, float((pg - p).abs().max()))
-    fps = len(times) / sum(times)
-    return dict(value=fps, unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'B32: 32 permanent frames preloaded (untimed), 1 warm-up + {len(times)} timed frames of '
-                       f'step()+argmax at 480x854, oracle/cpu_ref.py on {torch.get_num_threads()} threads '
-                       f'(host has {os.cpu_count()} logical CPUs)'), \
-        dict(mask_iou_vs_cpu_min=float(min(ious)), argmax_mismatch_pixels=mism, frames_compared=len(ious),
-             pixels_per_frame=H * W, max_abs_prob_err=perr)
+    del dev
+    ious, mism, perr = [], 0, 0.0
+    pos = [0]
+
+    def cpu_frames(n):
+        ts = []
+        for _ in range(n):
+            i = pos[0]; pos[0] += 1
+            t0 = time.perf_counter()
+            p = ref.step(torch.from_numpy(fr[idx_of(i)]), None, None)
+            m = R.post_process(p)
+            ts.append(time.perf_counter() - t0)
+            g, pg = gpu_out[i]
+            ious.append(R.compute_array_iou(g, m))
+            nonlocal mism, perr
+            mism += int((g != m).sum())
+            perr = max(perr, float((pg - p[:, 4::8, 4::8]).abs().max()))
+        return ts
+
+    sweep_fps = {}
+    for t, w, k in plan:
+        torch.set_num_threads(t)
+        cpu_frames(w)
+        sweep_fps[t] = 1.0 / float(np.median(cpu_frames(k)))
+    best_t = max(sweep_fps, key=sweep_fps.get)
+    torch.set_num_threads(best_t)
+    cpu_frames(3)
+    ts = cpu_frames(args.cpu_frames)
+    torch.set_num_threads(all_threads)
+    fps = 1.0 / float(np.median(ts))
+    return dict(value=fps, unit='frames/s', cores=best_t, kind='port',
+                one_thread_fps=sweep_fps.get(1), thread_sweep_fps={str(k): v for k, v in sweep_fps.items()},
+                host_logical_cpus=os.cpu_count(), frames_timed=len(ts), statistic='median',
+                sample=f'{wl["desc"]}: {wl["perm"]} permanent frames preloaded (untimed); thread sweep {sweep} '
+                       f'(1 warm-up + 3 timed frames each), then 3 warm-up + {len(ts)} timed frames of step()+argmax at the '
+                       f'best count ({best_t} threads); oracle/cpu_ref.py; host has {os.cpu_count()} logical CPUs'), \
+        dict(mask_iou_vs_cpu_min=float(min(ious)), mask_iou_vs_cpu_mean=float(np.mean(ious)), argmax_mismatch_pixels=mism,
+             frames_compared=len(ious), pixels_per_frame=wl['H'] * wl['W'], max_abs_prob_err_ds8=perr)
 
 
-def main():
+# ---- entry -------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--cpu-frames', type=int, default=8, help='timed frames of the CPU baseline leg (rank 0, N=1 only)')
+    ap.add_argument('--workload', default='b32', choices=sorted(WORKLOADS))
+    ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline at its best thread count')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefetch', action='store_true', help='do not pipeline the coming frames\' key encoder')
     ap.add_argument('--key-batch', type=int, default=4, help='frames per batched key-encoder hint (prefetch_keys)')
-    ap.add_argument('--dist-backend', default='nccl', help='control-plane backend for the timing barrier / max-reduce '
+    ap.add_argument('--no-kernel-trace', action='store_true', help='skip the rocprofv3 child run (kernel tables of the timed region)')
+    ap.add_argument('--trace-steps', type=int, default=60)
+    ap.add_argument('--trace-timeout', type=int, default=420)
+    ap.add_argument('--keep-trace', default=None, help='directory to keep the child\'s kernel_trace.csv in')
+    ap.add_argument('--traced-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--dist-backend', default='nccl', help='control-plane backend for the timing barrier / reductions '
                     '(nccl = RCCL; the data path has no collective)')
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
     torch.set_grad_enabled(False)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:                          # no torchrun environment: start the N ranks ourselves
+            codes = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+            sys.exit(max(abs(c) for c in codes))
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ['WORLD_SIZE'])
+        rank = int(os.environ.get('RANK', '0'))
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if world != args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
-    device = torch.device('cuda', local % torch.cuda.device_count())
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f'rank {rank}: device {local} requested but only {torch.cuda.device_count()} visible')
+    device = torch.device('cuda', local)
     torch.cuda.set_device(device)
+    backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # control plane only (timing barrier + max / sum of two scalars): RCCL by default
+        # control plane only (timing barrier + max / sum / gather of scalars): RCCL by default
         backend = args.dist_backend
         if backend == 'nccl':
             try:
@@ -245,52 +471,93 @@ def main():
     res = run_gpu(args, device, rank, world)
     elapsed = max_over_ranks(res['elapsed'], device)
     total_frames = sum_over_ranks(args.steps, device)
+    per_rank = [args.steps / e for e in gather_over_ranks(res['elapsed'], device)]
     fps = total_frames / elapsed
+    if args.traced_child:
+        print(json.dumps({'traced_child': True, 'fps_under_tracer': fps, 'steps': args.steps}), flush=True)
+        return
     if rank == 0:
-        alg = algorithmic_gflop_per_frame()
-        prof = res['prof']
-        conv = prof.get('conv', dict(ms=0.0, flop=0.0, launches=0))
-        aff = prof.get('affinity', dict(ms=0.0, flop=0.0, launches=0))
-        conv_tflops = conv['flop'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else None
-        aff_tflops = aff['flop'] / (aff['ms'] * 1e-3) / 1e12 if aff['ms'] > 0 else None
-        # HBM-side traffic per frame of the kernel families: PMC counters need rocprofv3 around the process, so bench.py
-        # reports the committed measurement of this same command (profiles/, separate --pmc passes, gfx950 correction)
-        traffic = {}
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_bench_b32_pmc_per_frame.json')) as f:
-                fam = json.load(f)['families']
-            traffic = {k: v['read_bytes'] + v['write_bytes'] for k, v in fam.items()}
-        except Exception:
-            pass
+        wl = res['wl']
+        alg = algorithmic_gflop_per_frame(wl, res['n_elems'])
+        nf = max(res['inst_frames'], 1)
+        aff = res['taps'].get('affinity')
+        ro = res['taps'].get('readout')
+        aff_ms = aff['ms'] / nf if aff else None
+        aff_gf = aff['flop'] / nf / 1e9 if aff else alg['similarity']
+        aff_tflops = (aff_gf / aff_ms) if aff_ms else None                     # GF / ms = TF/s
         line = {
-            'metric': 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference',
+            'metric': BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})',
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'B32: synthetic 480x854 clip, 1 object, 32 permanent memory frames (N=51840), '
-                                   'mem_every=1e9, step()+argmax per frame, conditioned synthetic weights',
-                       'replica_streams': world, 'top_k': TOPK, 'frame_pipelining': (not args.no_prefetch), 'key_batch': (args.key_batch if not args.no_prefetch else 0), 'parallelism': f'{world} independent streams, no collectives'},
-            'roofline': {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel (implicit GEMM / Winograd-domain GEMM, fp32 MFMA) + transforms',
-                         'achieved': conv_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (conv_tflops / PEAK_FP32_MFMA_TFLOPS) if conv_tflops else None, 'traffic': traffic.get('conv'),
-                         'traffic_unit': 'HBM-side bytes per frame of these launches (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_bench_b32_pmc_per_frame.json)',
-                         'measured': 'HIP events on the launch stream: every distinct convolution launch of one frame (un-hinted, batch-1 key encoder) timed over 10 back-to-back repetitions, Winograd transform kernels included; the timed region itself replays HIP graphs on two streams with batch-4 key passes',
-                         'launches_per_frame': conv['launches'] / max(res['prof_frames'], 1),
-                         'kernel_ms_per_frame': conv['ms'] / max(res['prof_frames'], 1),
-                         'algorithmic_gflop_per_frame': conv['flop'] / 1e9 / max(res['prof_frames'], 1)},
-            'affinity_roofline': {'bound': 'mfma', 'kernel': 'affinity_topk_kernel + merge (fused similarity/top-k/softmax)',
-                                  'achieved': aff_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                  'frac': (aff_tflops / PEAK_FP32_MFMA_TFLOPS) if aff_tflops else None,
-                                  'kernel_ms_per_frame': aff['ms'] / max(res['prof_frames'], 1),
-                                  'algorithmic_gflop_per_frame': alg['similarity'], 'traffic': traffic.get('affinity')},
+            'config': {'workload': wl['desc'] + '; step()+argmax+uint8 mask to host per frame, conditioned synthetic weights',
+                       'workload_key': args.workload, 'replica_streams': world, 'top_k': TOPK,
+                       'frame_pipelining': (not args.no_prefetch), 'key_batch': (args.key_batch if not args.no_prefetch else 0),
+                       'parallelism': f'{world} independent streams, no collectives',
+                       'control_plane': backend or 'none'},
+            'per_rank_fps': per_rank,
+            'roofline': {'bound': 'mfma',
+                         'kernel': 'xmem_affinity_topk: affinity_kernel (fused anisotropic-L2 similarity + exact top-k, fp32 MFMA) + bound / merge kernels',
+                         'achieved': aff_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (aff_tflops / PEAK_FP32_MFMA_TFLOPS) if aff_tflops else None, 'traffic': None,
+                         'algorithmic_gflop_per_frame': aff_gf, 'ms_per_frame': aff_ms,
+                         'calls_per_frame': (aff['calls'] / nf) if aff else None,
+                         'measured': f'HIP events on the launch stream around every xmem_affinity_topk call (all of its kernels) inside an '
+                                     f'instrumented pass of the timed schedule ({res["inst_frames"]} frames; HIP graphs, two streams, '
+                                     f'batch-{args.key_batch} key hints): SURVEY 8(d) F_sim = 4*C_k*N*HW per call / that time'},
+            'readout': {'ms_per_frame': (ro['ms'] / nf) if ro else None,
+                        'algorithmic_gflop_per_frame': (ro['flop'] / nf / 1e9) if ro else None,
+                        'bound': 'hbm', 'algorithmic_bytes_per_frame': 4.0 * CV * wl['K'] * TOPK * alg['hw'] + 4.0 * CV * wl['K'] * alg['hw']},
             'frame_gflop': alg, 'whole_frame_tflops': alg['total'] / 1e3 * fps / world,
+            'instrumented_pass_fps': (res['inst_frames'] / res['inst_elapsed']) if res['inst_elapsed'] else None,
             'preload_s_per_rank': res['preload_s'],
         }
+        if world == 1 and not args.no_kernel_trace:
+            tr, err = run_traced_child(args)
+            if tr is None:
+                line['kernel_trace'] = {'error': err}
+            else:
+                st = tr['steps']
+                fam = {k: dict(launches_per_frame=v[0] / st, us_per_frame=v[1] / st / 1e3) for k, v in tr['families'].items()}
+                top = sorted(tr['kernels'].items(), key=lambda kv: -kv[1][1])[:12]
+                line['kernel_trace'] = {
+                    'source': f'rocprofv3 --kernel-trace of a child copy of this command ({st} timed frames), cut to the timed region by marker kernels',
+                    'frames': st, 'wall_us_per_frame_under_tracer': tr['window_ns'] / st / 1e3,
+                    'gpu_busy_union': tr['busy_ns'] / tr['window_ns'], 'launches_per_frame': tr['launches'] / st,
+                    'families': fam,
+                    'top_kernels': [dict(kernel=k, launches_per_frame=v[0] / st, avg_us=v[1] / v[0] / 1e3, us_per_frame=v[1] / st / 1e3)
+                                    for k, v in top]}
+                conv_us = fam.get('conv', {}).get('us_per_frame')
+                aff_us = fam.get('affinity', {}).get('us_per_frame')
+                if conv_us:
+                    ctf = alg['conv'] / (conv_us * 1e-3)
+                    line['conv_roofline'] = {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel / Winograd-domain GEMMs + transform kernels',
+                                             'achieved': ctf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                             'frac': ctf / PEAK_FP32_MFMA_TFLOPS, 'frac_algorithmic': ctf / PEAK_FP32_MFMA_TFLOPS,
+                                             'algorithmic_gflop_per_frame': alg['conv'], 'us_per_frame': conv_us, 'traffic': None,
+                                             'note': 'algorithmic = the DIRECT convolution\'s FLOPs (SURVEY 8d); Winograd F(2x2,3x3) layers execute 2.25x fewer MFMA FLOPs, so the executed-MFMA fraction is lower: see mfma_busy'}
+                if aff_us:
+                    line['roofline']['timed_region_trace_us_per_frame'] = aff_us
+                    line['roofline']['frac_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
+        pmc = committed_pmc(args.workload)
+        if pmc is not None:
+            line['roofline']['traffic'] = pmc['families'].get('affinity')
+            line['roofline']['traffic_source'] = pmc['file'] + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this build; bytes per frame)'
+            if pmc.get('mfma_busy'):
+                line['roofline']['mfma_busy'] = pmc['mfma_busy'].get('affinity')
+            if 'conv_roofline' in line:
+                line['conv_roofline']['traffic'] = pmc['families'].get('conv')
+                if pmc.get('mfma_busy'):
+                    line['conv_roofline']['mfma_busy'] = pmc['mfma_busy'].get('conv')
         if world == 1 and not args.no_cpu_baseline:
-            cpu, parity = run_cpu_baseline(res, args, device)
-            line['cpu_baseline'] = cpu
-            line['parity'] = parity
-            line['speedup_vs_cpu'] = fps / cpu['value']
+            if args.workload in ('c4', 'c5'):
+                line['cpu_baseline'] = None
+                line['cpu_baseline_note'] = 'not run: the oracle materialises the N x HW affinity (13 GB / 136 GB per frame at this size)'
+            else:
+                cpu, parity = run_cpu_baseline(res, args, device)
+                line['cpu_baseline'] = cpu
+                line['parity'] = parity
+                line['speedup_vs_cpu'] = fps / cpu['value']
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -41,6 +41,11 @@ typedef enum {
 int xmem_version(void);                       /* ABI version, currently 1 */
 const char* xmem_last_error_string(int code); /* static string for a status code */
 
+/* Measurement aid: launches the empty kernel `xmem_trace_marker_kernel` on `stream`.  A rocprofv3 kernel trace of a
+ * process that brackets a region with two markers can be cut to exactly that region (bench.py does; the reference
+ * brackets the same region with perf_counter(), inference/run_on_video.py:106-113). */
+int xmem_trace_marker(int tag, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) with fused epilogue.
  * Replaces nn.Conv2d (+ eval BatchNorm2d + ReLU + residual add) call sites:

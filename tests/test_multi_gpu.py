@@ -48,7 +48,7 @@ def test_sharding_and_reduction_world2():
         assert p.exitcode == 0
     (r0, v0, t0, f0), (r1, v1, t1, f1) = res
     assert set(v0) | set(v1) == {f'v{i}' for i in range(7)} and not (set(v0) & set(v1))
-    assert v0[0] == 'v5' and v1[0] == 'v0'                      # longest-first, dealt round-robin
+    assert v0 == ['v5', 'v3', 'v4'] and v1 == ['v0', 'v2', 'v1', 'v6']   # longest first, each to the least-loaded rank
     assert t0 == t1 == 2.0 and f0 == f1 == 200
 
 
@@ -57,3 +57,70 @@ def test_shard_single_process():
     import bench
     assert bench.shard_videos(['a', 'b', 'c'], [1, 3, 2], 0, 1) == ['b', 'c', 'a']
     assert bench.max_over_ranks(1.5, torch.device('cpu')) == 1.5
+    assert bench.gather_over_ranks(2.5, torch.device('cpu')) == [2.5]
+    # equal lengths -> plain round-robin; every video exactly once for any world size
+    vids = list(range(11))
+    for world in (1, 2, 3, 8):
+        parts = [bench.shard_videos(vids, [7] * 11, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == vids
+        assert parts[0][:2] == ([0, 1] if world == 1 else [0, world])
+    with pytest.raises(ValueError):
+        bench.shard_videos(vids, [1] * 11, 2, 2)
+
+
+def _make_videos(root, lengths):
+    for i, n in enumerate(lengths):
+        for sub in ('JPEGImages', 'Annotations'):
+            d = root / sub / f'vid{i}'
+            d.mkdir(parents=True)
+            for t in range(n):
+                (d / f'{t:05d}{".jpg" if sub == "JPEGImages" else ".png"}').write_bytes(b'x')
+
+
+def test_launcher_world2_stub_runner(tmp_path):
+    """xmem2_amd.launch with 2 ranks (stub run_on_video, CPU): the union of the per-rank outputs is every video exactly
+    once, each rank processed the LPT share, and summary.json merges the per-rank results."""
+    import json
+    import subprocess
+    lengths = [9, 3, 7, 5, 2]
+    _make_videos(tmp_path, lengths)
+    out = tmp_path / 'out'
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, 'tests'))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, '-m', 'xmem2_amd.launch', '--gpus', '2', '--device', 'cpu', '--runner', 'stub_runner:run',
+                        '--videos', str(tmp_path / 'JPEGImages'), '--masks', str(tmp_path / 'Annotations'), '--out', str(out),
+                        '--frames-with-masks', '0', '--compute-iou', '--config', '{"size": -1}'],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    summ = json.load(open(out / 'summary.json'))
+    assert summ['n_gpus'] == 2 and summ['total_frames'] == sum(lengths) and not summ['ranks_missing']
+    by_rank = {0: [], 1: []}
+    for v in summ['videos']:
+        by_rank[v['rank']].append(v['name'])
+        assert abs(v['mean_iou'] - 0.5) < 1e-9
+    assert sorted(by_rank[0] + by_rank[1]) == [f'vid{i}' for i in range(5)]
+    assert set(by_rank[0]) == {'vid0', 'vid4', 'vid1'} and set(by_rank[1]) == {'vid2', 'vid3'}     # LPT: 9+2+3 | 7+5
+    for i, n in enumerate(lengths):
+        files = os.listdir(out / f'vid{i}' / 'masks')
+        assert len(files) == n
+        rank = 0 if f'vid{i}' in by_rank[0] else 1
+        assert open(out / f'vid{i}' / 'masks' / files[0]).read().startswith(f'rank {rank} local {rank}')
+
+
+def test_gpus_flag_is_not_silently_ignored():
+    """`--gpus 2` on a box with fewer than 2 devices must fail, never report a 1-GPU number as n_gpus 2 (bench and launcher);
+    under a torchrun environment a mismatching --gpus is refused as well."""
+    import subprocess
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n >= 2:
+        pytest.skip('box has >= 2 GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'refusing to run on fewer' in (p.stderr + p.stdout)
+    assert '"n_gpus"' not in p.stdout
+    env2 = dict(env, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env2, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'does not match WORLD_SIZE' in (p.stderr + p.stdout)

@@ -37,6 +37,7 @@ class ValueSegment(C.Structure):
 _SIGS = {
     'xmem_version': (C.c_int, []),
     'xmem_last_error_string': (C.c_char_p, [C.c_int]),
+    'xmem_trace_marker': (C.c_int, [C.c_int, C.c_void_p]),
     'xmem_conv2d_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'xmem_conv2d_nhwc': (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     'xmem_maxpool3x3s2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -30,6 +30,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_digest():
+    """sha256 over the kernel sources + header: profiles recorded for one build are only quoted against the same build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + ['common.hpp']):
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    with open(os.path.join(os.path.dirname(CSRC), '..', 'include', 'xmem_hip.h'), 'rb') as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB

@@ -6,6 +6,12 @@
 
 extern "C" int xmem_version(void) { return 1; }
 
+__global__ void xmem_trace_marker_kernel(int tag) { (void)tag; }
+extern "C" int xmem_trace_marker(int tag, void* stream) {
+    hipLaunchKernelGGL(xmem_trace_marker_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), tag);
+    return xmem_check_launch();
+}
+
 extern "C" const char* xmem_last_error_string(int code) {
     switch (code) {
         case XMEM_OK: return "ok";

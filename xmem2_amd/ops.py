@@ -22,6 +22,24 @@ _ws_suffix = ''
 # two HIP events (torch events record on the current stream, which is the stream every kernel here is launched on).
 RECORD = None
 PROFILE = None          # kept for compatibility: any non-None value also forces the eager (non-graph) path
+# EVENT_TAP = [] makes the memory-readout launches (which stay eager between the captured stages) bracket themselves with
+# HIP events ON THEIR LAUNCH STREAM inside whatever region is running - bench.py's instrumented pass of the timed region.
+EVENT_TAP = None
+
+
+def _tap_begin():
+    if EVENT_TAP is None:
+        return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0
+
+
+def _tap_end(kind, e0, flop):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        EVENT_TAP.append((kind, e0, e1, flop))
 
 
 def eager_only():
@@ -215,6 +233,11 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     return out
 
 
+def trace_marker(tag=0):
+    """Empty kernel `xmem_trace_marker_kernel` on the current stream: cuts a rocprofv3 kernel trace to a region."""
+    check(load().xmem_trace_marker(int(tag), stream_ptr()))
+
+
 def maxpool3x3s2(x):
     B, H, W, Cc = x.shape
     out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
@@ -396,8 +419,10 @@ def affinity_topk(segments, qk, qe, top_k, want_sim=False):
     sim = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device) if want_sim else None
     need = lib.xmem_affinity_topk_workspace_bytes(n_total, HW, top_k)
     ws = workspace(need, qk.device, 'affinity')
+    e0 = _tap_begin()
     check(lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
                                  ptr(ws), need, stream_ptr()))
+    _tap_end('affinity', e0, 4.0 * ck * n_total * HW)
     if RECORD is not None:
         RECORD.append(('affinity', f'{n_total}x{HW}k{top_k}', 4.0 * ck * n_total * HW,
                        lambda: lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
@@ -423,8 +448,10 @@ def readout_sparse(value_segments, w, idx, cv, out, out_ld, obj_stride, out_off=
             arr[o * n_seg + s].value = v.data_ptr() if v is not None and v.shape[0] > 0 else None
             arr[o * n_seg + s].n = v.shape[0] if v is not None else 0
     HW, k = w.shape
+    e0 = _tap_begin()
     check(load().xmem_readout_sparse(arr, n_obj, n_seg, ptr(w), ptr(idx), HW, k, cv,
                                      C.c_void_p(out.data_ptr() + 4 * out_off), out_ld, obj_stride, stream_ptr()))
+    _tap_end('readout', e0, 2.0 * cv * k * HW * n_obj)
 
 
 def similarity_dense(key, shrinkage, qk, qe):
