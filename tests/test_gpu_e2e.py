@@ -231,7 +231,10 @@ def test_prefetch_keys_is_only_a_hint(hip_net):
     assert cores[0].memory.temporary_work_mem.size == c.memory.temporary_work_mem.size
     for a, b in zip(plain, hinted):
         assert float((a - b).abs().max()) < 2e-3
-        assert float((ops.argmax_u8(a) != ops.argmax_u8(b)).float().mean()) < 1e-4
+        diff = ops.argmax_u8(a) != ops.argmax_u8(b)
+        assert float(diff.float().mean()) < 5e-4               # a handful of zero-margin pixels of 12288 may flip
+        top2 = torch.topk(a, 2, dim=0).values
+        assert not bool((diff & ((top2[0] - top2[1]) > 4e-3)).any()), 'argmax differs where the margin is clear'
     with pytest.raises(ValueError):
         c.prefetch_keys([fr[0], fr[1][:, :64]])
 

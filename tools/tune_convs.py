@@ -1,5 +1,6 @@
 """Run the B32 workload (and the test geometries) once with the autotuner on and dump the measured conv plans."""
 import os, sys
+os.environ.setdefault('XMEM_CONV_AUTOTUNE', '1')          # this tool IS the autotuner (off by default in the product)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 torch.set_grad_enabled(False)

@@ -119,8 +119,9 @@ def winograd_weights(w):
 # ---- convolution plans ---------------------------------------------------------------------------------------
 # Tile shape / split-K of the implicit-GEMM kernel are chosen per layer shape.  Plans measured on an MI355X are
 # shipped in conv_plans.json (deterministic: the same plan -> the same summation order); shapes not listed there
-# are timed once at first use (XMEM_CONV_AUTOTUNE=0 falls back to the library's built-in heuristic).
-AUTOTUNE = os.environ.get('XMEM_CONV_AUTOTUNE', '1') != '0'
+# take the library's built-in deterministic heuristic (same shape -> same tiles -> same summation order on every machine).
+# XMEM_CONV_AUTOTUNE=1 opts in to timing the candidates at first use (tools/tune_convs.py does, to refresh conv_plans.json).
+AUTOTUNE = os.environ.get('XMEM_CONV_AUTOTUNE', '0') == '1'
 _PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_plans.json')
 _plans = None
 _tuned_now = {}
