@@ -179,6 +179,22 @@ int xmem_affinity_topk(const xmem_key_segment* segs_host, int n_seg,
                        float* out_w, int32_t* out_idx, float* out_sim,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same function with an optional HINT: `idx` are the out_idx [HW][top_k] of an earlier call on the same list of stores (the
+ * previous frame of the video), `seg_n` the segment sizes of that call, `grid_w` the width of the stride-16 query grid (0: do not
+ * use grid neighbours).  The hint only replaces the sampled pass that bounds the k-th similarity from below (any k distinct
+ * elements give a valid bound; the previous frame's matches give a tight one): results are identical with and without it.
+ * hint == NULL behaves as xmem_affinity_topk.  The reference recomputes everything per frame (memory_manager.py:82-120). */
+typedef struct {
+    const int32_t* idx; int top_k;
+    int n_seg; int seg_n[XMEM_MAX_SEGMENTS];
+    int grid_w;
+} xmem_affinity_hint;
+int xmem_affinity_topk_hinted(const xmem_key_segment* segs_host, int n_seg,
+                              const float* qk, const float* qe, int Ck, int HW, int top_k,
+                              const xmem_affinity_hint* hint,
+                              float* out_w, int32_t* out_idx, float* out_sim,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* usage = affinity.sum(dim=2) (memory_util.py:62-63) restricted to [first, first+count) of the index space,
  * accumulated order-independently (64-bit fixed point) and then folded into the store counters as
  * KeyValueMemoryStore.update_usage does (kv_memory_store.py:96-103): use_count += usage; life_count += 1.

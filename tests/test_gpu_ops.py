@@ -410,6 +410,41 @@ def test_affinity_optimistic_overflow_falls_back_exactly():
     close(dense, aff.t(), 2e-4, 1e-7, 'affinity after fallback')
 
 
+def test_affinity_hint_never_changes_the_result():
+    """xmem_affinity_topk_hinted: the hint (previous top-k indices) only bounds the k-th similarity from below.  Results
+    with a perfect hint, a hint from a DIFFERENT segment layout, a hint of k' > k indices, a garbage hint (all zeros:
+    fewer than k distinct elements -> no bound -> safe kernel) and a misleading hint (the WORST elements: a very loose bound
+    -> candidate lists overflow -> safe kernel) must all equal the un-hinted result."""
+    from xmem2_amd import ops
+    gen = g_(91)
+    n, hw, gw = 20000, 300, 20
+    mk = torch.randn(n, 64, generator=gen) * 0.9
+    ms = torch.rand(n, generator=gen) * 3 + 1
+    qk = torch.randn(hw, 64, generator=gen) * 0.9
+    qe = torch.rand(hw, 64, generator=gen) * 0.9 + 0.05
+    cuts = [0, 7000, 7000, 20000]                                  # three slots, the middle one empty
+    segs = [(mk[a:b].cuda() if b > a else None, ms[a:b].cuda() if b > a else None) for a, b in zip(cuts[:-1], cuts[1:])]
+    sizes = [b - a for a, b in zip(cuts[:-1], cuts[1:])]
+    w0, i0, s0 = ops.affinity_topk(segs, qk.cuda(), qe.cuda(), 30, want_sim=True)
+    sim = R.get_similarity(mk.t().unsqueeze(0), ms.view(1, 1, -1), qk.t().unsqueeze(0), qe.t().unsqueeze(0))
+    _check_topk(w0, i0, sim, 30, 'un-hinted')
+    worst = torch.topk(sim[0], 40, dim=0, largest=False)[1].t().contiguous().int().cuda()       # [hw, 40]
+    _, i64, _ = ops.affinity_topk(segs, qk.cuda(), qe.cuda(), 64)
+    hints = {
+        'perfect': (i0, sizes, gw),
+        'perfect, no neighbours': (i0, sizes, 0),
+        'k=64 hint': (i64, sizes, gw),
+        'other layout': (i0, [5000, 3000, 12000], gw),
+        'garbage': (torch.zeros_like(i0), sizes, gw),
+        'misleading': (worst, sizes, 0),
+    }
+    for name, h in hints.items():
+        w, i, sv = ops.affinity_topk(segs, qk.cuda(), qe.cuda(), 30, want_sim=True, hint=h)
+        torch.cuda.synchronize()
+        assert torch.equal(sv, s0), f'{name}: similarities differ from the un-hinted call'
+        assert torch.equal(i, i0) and torch.equal(w, w0), f'{name}: indices / weights differ from the un-hinted call'
+
+
 # ---------------------------------------------------------------------------------------------------------
 # consolidation kernels
 # ---------------------------------------------------------------------------------------------------------

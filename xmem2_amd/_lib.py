@@ -30,6 +30,10 @@ class KeySegment(C.Structure):
     _fields_ = [('key', C.c_void_p), ('shrinkage', C.c_void_p), ('n', C.c_int)]
 
 
+class AffinityHint(C.Structure):
+    _fields_ = [('idx', C.c_void_p), ('top_k', C.c_int), ('n_seg', C.c_int), ('seg_n', C.c_int * 4), ('grid_w', C.c_int)]
+
+
 class ValueSegment(C.Structure):
     _fields_ = [('value', C.c_void_p), ('n', C.c_int)]
 
@@ -65,6 +69,8 @@ _SIGS = {
     'xmem_affinity_topk_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'xmem_affinity_topk': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'xmem_affinity_topk_hinted': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(AffinityHint), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'xmem_usage_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'xmem_readout_sparse': (C.c_int, [C.POINTER(ValueSegment), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),

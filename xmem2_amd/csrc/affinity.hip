@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffA
 }
 
 // bound pass reduction: tau0[q] = k-th largest of the survivors of all splits (one wave per query)
-__global__ void affinity_bound_kernel(const float* __restrict__ bound_part, int splits, int HW, int top_k, float* __restrict__ tau0) {
+__global__ void affinity_bound_kernel(const float* __restrict__ bound_part, int splits, int HW, int top_k, float* __restrict__ tau0,
+                                      int* __restrict__ gcnt, int* __restrict__ ovf) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int T = splits * AFF_BOUND_SLOTS;
@@ -376,7 +377,7 @@ __global__ void affinity_bound_kernel(const float* __restrict__ bound_part, int 
         if (rk == top_k - 1) res = ve;
     }
     res = wave_max(res);
-    if (lane == 0) tau0[q] = res;
+    if (lane == 0) { tau0[q] = res; gcnt[q] = 0; if ((q & 63) == 0) ovf[q >> 6] = 0; }
 }
 
 // one wave per query: rank the candidates of all splits, emit sorted top-k + softmax weights
@@ -449,6 +450,354 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
     }
 }
 
+
+// =================================================================================================================
+// Wide select (large memories): 128 queries x 32-row tiles per wave, 8 waves per workgroup, ONE workgroup per CU.
+//   * every key row is loaded by exactly one wave of the workgroup and contracted against 128 queries (four independent
+//     32x32 accumulator chains): half the L2 -> CU key traffic of the 64-query kernel and no dependent-MFMA stalls;
+//   * no accumulator double buffering: the two waves that share a SIMD cover each other's (short) VALU filter phase;
+//   * candidates (v > tau0) go to per-query LDS lists and are flushed once, at the end, to ONE global list per query
+//     (atomic reservation), so the merge reads a single contiguous list per query instead of one list per split;
+//   * a full LDS / global list only raises the 64-query tile's overflow flag: the safe kernel (MODE 3) redoes that tile.
+// tau0 comes either from the sampled bound pass (MODE 0) or from `affinity_hint_bound_kernel` below.
+// =================================================================================================================
+#define AFW_BQ 128
+#define AFW_WAVES 8
+#define AFW_CAP 80          // per (workgroup, query) LDS candidates
+#define AFW_GCAP 256        // per-query global candidate list (all splits)
+
+struct WideArgs {
+    SegDev seg[XMEM_MAX_SEGMENTS];
+    int n_seg, total_tiles;
+    const float* qk; const float* qe;
+    int HW, top_k;
+    int splits, tiles_per_split, chunk, sub_tiles;
+    const float* tau_init;           // [HW] valid lower bound of the k-th similarity (-inf: no bound -> tile goes to the safe kernel)
+    u64* gcand; int* gcnt;           // [HW][AFW_GCAP], [HW] (zeroed by the bound kernels)
+    int* ovf;                        // [ceil(HW/64)]
+};
+
+__global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
+    constexpr int CK = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Bq = smem;                                 // [128][132]
+    float* bsq = Bq + AFW_BQ * AFF_LDB;               // [128]
+    float* tau = bsq + AFW_BQ;                        // [128]
+    int* cnt = reinterpret_cast<int*>(tau + AFW_BQ);  // [128]
+    u64* cand = reinterpret_cast<u64*>(cnt + AFW_BQ); // [128][AFW_CAP]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * AFW_BQ;
+    const int split = blockIdx.y;
+
+    {   // stage the query operand (same arithmetic as affinity_kernel: bit-identical similarities)
+        const int q = tid >> 2, part = tid & 3, qg = q0 + q;
+        float bs = 0.f;
+        float* row = Bq + q * AFF_LDB;
+        if (qg < p.HW) {
+            const float* kq = p.qk + (size_t)qg * CK + part * 16;
+            const float* eq = p.qe ? p.qe + (size_t)qg * CK + part * 16 : nullptr;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float k = kq[c];
+                const float e = eq ? eq[c] : 1.f;
+                row[part * 16 + c] = -e;
+                row[CK + part * 16 + c] = 2.f * (k * e);
+                bs += e * (k * k);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { row[part * 16 + c] = 0.f; row[CK + part * 16 + c] = 0.f; }
+        }
+        bs += __shfl_xor(bs, 1, 64);
+        bs += __shfl_xor(bs, 2, 64);
+        if (part == 0) {
+            bsq[q] = p.qe ? bs : 0.f;
+            float t0 = (qg < p.HW) ? p.tau_init[qg] : INFINITY;
+            if (t0 == -INFINITY) { p.ovf[qg >> 6] = 1; t0 = INFINITY; }      // no usable bound: the safe kernel owns this tile
+            tau[q] = (t0 == INFINITY) ? INFINITY : nextafterf(t0, -INFINITY);
+            cnt[q] = 0;
+        }
+    }
+    __syncthreads();
+
+    const int t_begin = p.chunk ? 0 : split * p.tiles_per_split;
+    const int t_end = p.chunk ? p.tiles_per_split : min(p.sub_tiles, t_begin + p.tiles_per_split);
+
+    f32x4 an[8]; float msn = 1.f;
+    int n_segn = 0, n_base = 0, n_row0 = 0; bool n_active = false;
+    auto issue_loads = [&](int tile) {
+        bool off = tile >= t_end;
+        if (p.chunk && !off) {
+            const int ci = tile / p.chunk, wi = tile - ci * p.chunk;
+            tile = (ci * p.splits + split) * p.chunk + wi;
+            off = tile >= p.sub_tiles;
+        }
+        n_active = !off;
+        const float* key = nullptr; const float* shr = nullptr;
+        n_segn = 0; n_base = 0; n_row0 = 0;
+        if (!off) {
+            int s = 0;
+#pragma unroll
+            for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+                if (i < p.n_seg && tile >= p.seg[i].tile0) s = i;
+            key = p.seg[s].key; shr = p.seg[s].shr; n_segn = p.seg[s].n; n_base = p.seg[s].base;
+            n_row0 = (tile - p.seg[s].tile0) * AFF_ROWS;
+        }
+        const int r = n_row0 + l31;
+        const bool ok = n_active && r < n_segn;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const float* src = key + (size_t)r * CK + lh * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) an[t] = ok ? *reinterpret_cast<const f32x4*>(src + t * 8) : zero;
+        msn = (ok && shr) ? shr[r] : 1.f;
+    };
+
+    float my_tau[4], my_bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { my_tau[i] = tau[i * 32 + l31]; my_bs[i] = bsq[i * 32 + l31]; }
+    constexpr float inv_sqrt = 0.125f;               // sqrt(C_k) = 8: (x * ms) / 8 == x * (ms / 8) bit for bit
+
+    issue_loads(t_begin + wave);
+    for (int tb = t_begin; tb < t_end; tb += AFW_WAVES) {
+        f32x4 a[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = an[t];
+        const float ms_mine = msn;
+        const bool have = n_active;
+        const int row0 = n_row0, segn = n_segn, base = n_base;
+        issue_loads(tb + AFW_WAVES + wave);           // next tile's rows in flight under this tile's MFMAs
+        if (!have) continue;
+        f32x16 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[i][r] = -my_bs[i];
+        const float* bq = Bq + l31 * AFF_LDB + lh * 4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x4 blo[4], bhi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                blo[i] = *reinterpret_cast<const f32x4*>(bq + i * 32 * AFF_LDB + t * 8);
+                bhi[i] = *reinterpret_cast<const f32x4*>(bq + i * 32 * AFF_LDB + CK + t * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = a[t][j];
+                const float xx = x * x;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xx, blo[i][j], c[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, bhi[i][j], c[i], 0, 0, 0);
+            }
+        }
+        float msr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) msr[r] = __shfl(ms_mine, (r & 3) + 8 * (r >> 2) + 4 * lh, 64) * inv_sqrt;
+        const bool full = row0 + AFF_ROWS <= segn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float best = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float x = c[i][r] * msr[r];
+                best = fmaxf(best, (full || rr < segn) ? x : -INFINITY);
+            }
+            if (best > my_tau[i]) {                    // rare: walk the 16 values of this lane
+                const int q = i * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float x = c[i][r] * msr[r];
+                    if (rr < segn && x > my_tau[i]) {
+                        const int slot = atomicAdd(&cnt[q], 1);
+                        if (slot < AFW_CAP) cand[(size_t)q * AFW_CAP + slot] = pack_key(x, base + rr);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- flush: reserve room in the query's global list, copy; any truncation flags the 64-query tile ----
+    for (int q = wave; q < AFW_BQ; q += AFW_WAVES) {
+        const int qg = q0 + q;
+        if (qg >= p.HW) continue;
+        int c = cnt[q];
+        if (c == 0) continue;
+        bool over = c > AFW_CAP;
+        c = over ? AFW_CAP : c;
+        int gb = 0;
+        if (lane == 0) gb = atomicAdd(&p.gcnt[qg], c);
+        gb = __shfl(gb, 0, 64);
+        if (gb + c > AFW_GCAP) over = true;
+        if (over && lane == 0) p.ovf[qg >> 6] = 1;
+        for (int s2 = lane; s2 < c && gb + s2 < AFW_GCAP; s2 += 64) p.gcand[(size_t)qg * AFW_GCAP + gb + s2] = cand[(size_t)q * AFW_CAP + s2];
+    }
+}
+
+// Bound from a hint: `hint_idx` holds k_h indices per query from an EARLIER call (the previous frame's top-k of the same
+// store list).  Any k distinct memory elements give a valid lower bound of the k-th largest similarity: the k-th largest
+// of their similarities.  In a video the previous frame's matches of a query and of its four grid neighbours are nearly
+// the current ones, so this bound is far tighter than a sampled pass (and costs ~k rows per query instead of N/4).
+// The similarities are evaluated on the VALU in a different summation order than the MFMA chain of the select kernels;
+// a rigorous fp32 bound on that difference (2 * 128 * 2^-24 * sum|terms|) is subtracted, so "at least k elements pass
+// tau0" holds for the values the select kernel computes.  Also zeroes the per-query list counters and overflow flags.
+struct HintArgs {
+    SegDev seg[XMEM_MAX_SEGMENTS]; int n_seg, n_total;
+    int old_n[XMEM_MAX_SEGMENTS]; int new_of_old[XMEM_MAX_SEGMENTS]; int old_seg;   // segment slots of the call that produced hint_idx
+    const int* hint_idx; int hint_k; int grid_w;
+    const float* qk; const float* qe; int HW, top_k;
+    float* tau0; int* gcnt; int* ovf;
+};
+#define HINT_MAXC 320       // 5 queries x 64 indices
+
+__global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
+    constexpr int CK = 64;
+    __shared__ __attribute__((aligned(16))) float s_op[4][2 * CK];
+    __shared__ float s_val[4][HINT_MAXC];
+    __shared__ int s_idx[4][HINT_MAXC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= p.HW) return;
+    float* op = s_op[wv]; float* val = s_val[wv]; int* ix = s_idx[wv];
+    // query operands (-e | 2ke) and b_sq
+    float bs = 0.f;
+    {
+        const float k = p.qk[(size_t)q * CK + lane];
+        const float e = p.qe ? p.qe[(size_t)q * CK + lane] : 1.f;
+        op[lane] = -e; op[CK + lane] = 2.f * (k * e);
+        bs = p.qe ? e * (k * k) : 0.f;
+    }
+    bs = wave_sum(bs);
+    if (lane == 0) { p.gcnt[q] = 0; if ((q & 63) == 0) p.ovf[q >> 6] = 0; }
+    // candidate indices: this query and its grid neighbours in the hint, re-based from the old segment layout to the new one
+    int nq[5]; int nn = 0;
+    nq[nn++] = q;
+    if (p.grid_w > 0) {
+        const int x = q % p.grid_w;
+        if (x > 0) nq[nn++] = q - 1;
+        if (x + 1 < p.grid_w && q + 1 < p.HW) nq[nn++] = q + 1;
+        if (q >= p.grid_w) nq[nn++] = q - p.grid_w;
+        if (q + p.grid_w < p.HW) nq[nn++] = q + p.grid_w;
+    }
+    const int T = nn * p.hint_k;
+    for (int e = lane; e < T; e += 64) {
+        const int src = nq[e / p.hint_k], j = e - (e / p.hint_k) * p.hint_k;
+        int o = p.hint_idx[(size_t)src * p.hint_k + j];
+        int sgi = 0, ob = 0;
+#pragma unroll
+        for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i)
+            if (i + 1 < p.old_seg && o >= ob + p.old_n[i]) { ob += p.old_n[i]; sgi = i + 1; }
+        o -= ob;
+        sgi = p.new_of_old[sgi];
+        if (sgi >= p.n_seg) sgi = p.n_seg - 1;
+        if (o < 0) o = 0;
+        if (o >= p.seg[sgi].n) o = p.seg[sgi].n - 1;
+        ix[e] = p.seg[sgi].base + o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // similarity lower estimates (duplicates -> -inf so that k DISTINCT elements back the bound)
+    for (int e = lane; e < T; e += 64) {
+        const int gi = ix[e];
+        bool dup = false;
+        for (int f = 0; f < e; ++f) dup |= (ix[f] == gi);
+        float v = -INFINITY;
+        if (!dup) {
+            int sgi = 0;
+#pragma unroll
+            for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+                if (i < p.n_seg && gi >= p.seg[i].base) sgi = i;
+            const int o = gi - p.seg[sgi].base;
+            const float* row = p.seg[sgi].key + (size_t)o * CK;
+            float acc = 0.f, aacc = 0.f;
+#pragma unroll 4
+            for (int c4 = 0; c4 < CK; c4 += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(row + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = x[j], xx = xv * xv;
+                    const float t1 = xx * op[c4 + j], t2 = xv * op[CK + c4 + j];
+                    acc += t1; acc += t2;
+                    aacc += fabsf(t1) + fabsf(t2);
+                }
+            }
+            const float ms = p.seg[sgi].shr ? p.seg[sgi].shr[o] : 1.f;
+            const float sc = fabsf(ms) * 0.125f;
+            const float est = (acc - bs) * (ms * 0.125f);
+            const float margin = (aacc + fabsf(bs)) * sc * 3.2e-5f + 1e-30f;      // > 2 * 130 * 2^-24 * sum|terms| (+ the two scalings)
+            v = est - margin;
+        }
+        val[e] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float res = -INFINITY;                           // stays -inf with fewer than k distinct candidates
+    for (int e = lane; e < T; e += 64) {
+        const float ve = val[e];
+        if (ve == -INFINITY) continue;
+        int rk = 0;
+        for (int f = 0; f < T; ++f) { const float vf = val[f]; rk += (vf > ve) || (vf == ve && f < e); }
+        if (rk == p.top_k - 1) res = ve;
+    }
+    res = wave_max(res);
+    if (lane == 0) p.tau0[q] = res;
+}
+
+// Merge for the wide select: 16 lanes per query (4 queries per wave).  Source: the query's global list, or - when its
+// 64-query tile overflowed - the per-split lists written by the safe kernel.  Rank by counting (keys are unique: the
+// index is part of the key), sorted top-k, softmax without max shift (memory_util.py:48-49).
+#define AFM_MAXT 384
+__global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __restrict__ gcand, const int* __restrict__ gcnt,
+                                                               const int* __restrict__ ovf, const u64* __restrict__ part_key,
+                                                               const int* __restrict__ part_cnt, int fsplits, int HW, int top_k,
+                                                               float* __restrict__ out_w, int* __restrict__ out_idx,
+                                                               float* __restrict__ out_sim) {
+    __shared__ __attribute__((aligned(16))) u64 s_keys[16][AFM_MAXT + 2];
+    __shared__ float s_v[16][AFF_MAX_TOPK];
+    __shared__ int s_i[16][AFF_MAX_TOPK];
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int q = blockIdx.x * 16 + g;
+    if (q >= HW) return;
+    u64* keys = s_keys[g]; float* sv = s_v[g]; int* si = s_i[g];
+    int total = 0;
+    if (ovf[q >> 6]) {
+        for (int s = 0; s < fsplits; ++s) {
+            int c = part_cnt[(size_t)s * HW + q];
+            if (total + c > AFM_MAXT) c = AFM_MAXT - total;
+            for (int e = l; e < c; e += 16) keys[total + e] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + e];
+            total += c;
+        }
+    } else {
+        total = gcnt[q];
+        if (total > AFW_GCAP) total = AFW_GCAP;
+        for (int e = l; e < total; e += 16) keys[e] = gcand[(size_t)q * AFW_GCAP + e];
+    }
+    if (l == 0) keys[total] = 0ull;
+    __builtin_amdgcn_wave_barrier();                  // the 16 lanes of a group are one quarter of a wave: LDS ops are in order
+    for (int e = l; e < total; e += 16) {
+        const u64 ke = keys[e];
+        int rk = 0;
+        for (int f = 0; f < total; f += 2) {
+            const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(keys + f);
+            rk += (int)(kf.x > ke) + (int)((f + 1 < total) && (kf.y > ke));
+        }
+        if (rk < top_k) { sv[rk] = key_val(ke); si[rk] = key_idx(ke); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float s = 0.f;
+    for (int r = l; r < top_k; r += 16) s += expf(sv[r]);
+    s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+    for (int r = l; r < top_k; r += 16) {
+        const float v = sv[r];
+        out_w[(size_t)q * top_k + r] = expf(v) / s;
+        out_idx[(size_t)q * top_k + r] = si[r];
+        if (out_sim) out_sim[(size_t)q * top_k + r] = v;
+    }
+}
+
 namespace {
 struct AffPlan { int splits, tiles_per_split, sub_tiles, limit, cap; size_t lds; };
 
@@ -507,18 +856,22 @@ inline int bound_stride(int total_tiles) {
     return total_tiles >= 256 ? 4 : 1;
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, spill_off, total; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, total; int fsplits; };
+// fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
+inline int fallback_splits(int HW) { const int qt = cdiv(HW, AFF_BQ); int fs = 128 / qt; if (fs < 1) fs = 1; if (fs > 4) fs = 4; return fs; }
 WsLayout ws_layout(int HW) {
     WsLayout w;
-    w.key_off = 0;
+    w.fsplits = fallback_splits(HW);
+    w.key_off = 0;                                                     // [<= 64 splits][HW][AFF_OUTCAP] (MODE 2 / MODE 3 lists)
     w.cnt_off = align_up((size_t)64 * HW * AFF_OUTCAP * sizeof(u64), 256);
     w.bound_off = w.cnt_off + align_up((size_t)64 * HW * sizeof(int), 256);
     w.tau_off = w.bound_off + align_up((size_t)AFF_MAX_BOUND_SPLITS * HW * AFF_BOUND_SLOTS * sizeof(float), 256);
     w.ovf_off = w.tau_off + align_up((size_t)HW * sizeof(float), 256);
-    w.spill_off = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
-    // fallback buffers: one per workgroup of the select grid (query tiles x splits <= max(512, query tiles)), cap = 96 + 128
-    const size_t wgs = cdiv(HW, AFF_BQ) > 512 ? (size_t)cdiv(HW, AFF_BQ) : 512;
-    w.total = w.spill_off + wgs * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64);
+    w.gcand_off = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
+    w.gcnt_off = w.gcand_off + align_up((size_t)HW * AFW_GCAP * sizeof(u64), 256);
+    w.spill_off = w.gcnt_off + align_up((size_t)HW * sizeof(int), 256);
+    // fallback buffers: one per workgroup of its grid (64-query tiles x fsplits), cap = 96 + 128
+    w.total = w.spill_off + (size_t)cdiv(HW, AFF_BQ) * w.fsplits * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64);
     return w;
 }
 }  // namespace
@@ -528,18 +881,21 @@ extern "C" size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int to
     return ws_layout(HW).total;
 }
 
-extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const float* qk, const float* qe, int Ck, int HW,
-                                  int top_k, float* out_w, int32_t* out_idx, float* out_sim,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg, const float* qk, const float* qe, int Ck, int HW,
+                                         int top_k, const xmem_affinity_hint* hint, float* out_w, int32_t* out_idx, float* out_sim,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!segs || n_seg <= 0 || n_seg > XMEM_MAX_SEGMENTS || !qk || !out_w || !out_idx || HW <= 0) return XMEM_ERR_BAD_ARG;
     if (Ck != 64) return XMEM_ERR_UNSUPPORTED;
     if (top_k < 1 || top_k > AFF_MAX_TOPK) return XMEM_ERR_UNSUPPORTED;
     AffArgs a;
     int tiles = 0, base = 0, ns = 0;
+    int pos_map[XMEM_MAX_SEGMENTS];                     // caller's segment slot -> compacted (non-empty) segment, or -1
     for (int i = 0; i < n_seg; ++i) {
         if (segs[i].n < 0) return XMEM_ERR_BAD_ARG;
+        pos_map[i] = -1;
         if (segs[i].n == 0) { continue; }
         if (!segs[i].key) return XMEM_ERR_BAD_ARG;
+        pos_map[i] = ns;
         a.seg[ns].key = segs[i].key; a.seg[ns].shr = segs[i].shrinkage; a.seg[ns].n = segs[i].n;
         a.seg[ns].base = base; a.seg[ns].tile0 = tiles; a.seg[ns].pad = 0;
         tiles += cdiv(segs[i].n, AFF_ROWS); base += segs[i].n; ++ns;
@@ -556,21 +912,71 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
     a.part_cnt = reinterpret_cast<int*>(ws + wl.cnt_off);
     a.bound_part = reinterpret_cast<float*>(ws + wl.bound_off);
     float* tau0 = reinterpret_cast<float*>(ws + wl.tau_off);
+    int* ovf = reinterpret_cast<int*>(ws + wl.ovf_off);
+    u64* gcand = reinterpret_cast<u64*>(ws + wl.gcand_off);
+    int* gcnt = reinterpret_cast<int*>(ws + wl.gcnt_off);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    int R = bound_stride(tiles);
-    AffPlan pl = aff_plan(tiles, HW, top_k, false);
-    // large memories: chunks of ~half a memory frame are dealt round-robin to the select splits (see the kernel), but only
-    // when every split gets >= 16 chunks (load imbalance <= 1/16)
-    int sel_chunk = cdiv(HW, AFF_ROWS) / 2; if (sel_chunk < 8) sel_chunk = 8;
-    const int n_chunks = cdiv(pl.sub_tiles, sel_chunk);
-    if (n_chunks < 16 * pl.splits) sel_chunk = 0;
-    // with the candidates spread evenly the looser bound of an every-8th-tile sample still fits the buffers (12.5 % extra work)
-    if (sel_chunk && tiles >= 8192) R = 8;
-    a.tau_init = nullptr;
-    a.ovf = nullptr;
-    a.cand_spill = nullptr;
-    if (R > 1) {
+    a.tau_init = nullptr; a.ovf = nullptr; a.cand_spill = nullptr; a.merge_splits = 0;
+
+    if (tiles < 256 || top_k > AFW_CAP) {
+        // ---- small memories: one safe pass (worst-case LDS buffers + exact re-rank valve), per-split lists, wave-per-query merge
+        AffPlan pl = aff_plan(tiles, HW, top_k, false);
+        a.limit = pl.limit; a.cap = pl.cap; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
+        a.tile_stride = 1; a.chunk = 0;
+        auto kern = affinity_kernel<64, 2>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
+            return XMEM_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        const size_t mlds = ((size_t)pl.splits * AFF_OUTCAP + 2) * sizeof(u64) + (size_t)2 * top_k * sizeof(float);
+        hipLaunchKernelGGL(affinity_merge_kernel, dim3(HW), dim3(64), mlds, s, a.part_key, a.part_cnt, pl.splits, HW, top_k,
+                           out_w, out_idx, out_sim);
+        return xmem_check_launch();
+    }
+
+    // ---- large memories: bound (hint or sampled pass) -> wide select -> safe kernel on overflowed tiles -> merge ----
+    const int qt128 = cdiv(HW, AFW_BQ);
+    WideArgs w;
+    for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) w.seg[i] = a.seg[i];
+    w.n_seg = ns; w.total_tiles = tiles; w.qk = qk; w.qe = qe; w.HW = HW; w.top_k = top_k;
+    w.tau_init = tau0; w.gcand = gcand; w.gcnt = gcnt; w.ovf = ovf;
+    // one 8-wave workgroup per CU: splits so that query tiles x splits fills (at most) the 256 CUs, >= 8 tiles per wave
+    int sp = 256 / qt128; if (sp < 1) sp = 1;
+    { int maxs = tiles / (8 * AFW_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
+    if (sp > 64) sp = 64;
+    w.sub_tiles = tiles;
+    w.tiles_per_split = cdiv(tiles, sp);
+    w.splits = cdiv(tiles, w.tiles_per_split);
+    // chunks of ~half a memory frame dealt round-robin to the splits (temporal clusters of good matches would otherwise pile
+    // up in one split's candidate lists), when every split gets >= 16 chunks
+    int sel_chunk = cdiv(HW, AFF_ROWS) / 2; if (sel_chunk < AFW_WAVES) sel_chunk = AFW_WAVES;
+    sel_chunk = cdiv(sel_chunk, AFW_WAVES) * AFW_WAVES;
+    const int n_chunks = cdiv(tiles, sel_chunk);
+    if (n_chunks < 16 * w.splits) sel_chunk = 0;
+    w.chunk = sel_chunk;
+    if (sel_chunk) w.tiles_per_split = cdiv(n_chunks, w.splits) * sel_chunk;
+
+    const bool hinted = hint && hint->idx && hint->top_k >= top_k && hint->top_k <= 64 && hint->n_seg == n_seg;
+    if (hinted) {
+        HintArgs h;
+        for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) { h.seg[i] = a.seg[i]; h.old_n[i] = 0; }
+        h.n_seg = ns; h.n_total = base;
+        int last = 0;                                   // old slot -> today's compacted segment of the same slot (or a neighbour)
+        for (int i = 0; i < n_seg; ++i) {
+            h.old_n[i] = hint->seg_n[i] > 0 ? hint->seg_n[i] : 0;
+            if (pos_map[i] >= 0) last = pos_map[i];
+            h.new_of_old[i] = pos_map[i] >= 0 ? pos_map[i] : last;
+        }
+        h.old_seg = n_seg;
+        h.hint_idx = hint->idx; h.hint_k = hint->top_k; h.grid_w = hint->grid_w > 0 ? hint->grid_w : 0;
+        h.qk = qk; h.qe = qe; h.HW = HW; h.top_k = top_k; h.tau0 = tau0; h.gcnt = gcnt; h.ovf = ovf;
+        hipLaunchKernelGGL(affinity_hint_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), 0, s, h);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    } else {
+        // sampled bound pass: every 4th 32-row tile (every 8th for very large chunk-dealt memories)
+        int R = 4;
+        if (sel_chunk && tiles >= 8192) R = 8;
         AffPlan pa = aff_plan(cdiv(tiles, R), HW, top_k, true, base);
         a.cap = 0; a.limit = 0; a.splits = pa.splits; a.tiles_per_split = pa.tiles_per_split; a.sub_tiles = pa.sub_tiles;
         a.tile_stride = R; a.chunk = 0;
@@ -578,49 +984,39 @@ extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         const int T = pa.splits * AFF_BOUND_SLOTS;
         hipLaunchKernelGGL(affinity_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), (size_t)4 * T * sizeof(float), s,
-                           a.bound_part, pa.splits, HW, top_k, tau0);
-        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-        a.tau_init = tau0;
-    }
-    a.limit = pl.limit; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
-    a.tile_stride = 1;
-    a.chunk = sel_chunk;
-    if (sel_chunk) a.tiles_per_split = cdiv(n_chunks, pl.splits) * sel_chunk;   // local visit indices per split (some map past the end)
-    if (R > 1 && top_k <= AFF_OPT_CAP) {
-        // optimistic select with the bound in hand, then the safe kernel on the (normally zero) overflowed query tiles
-        a.ovf = reinterpret_cast<int*>(ws + wl.ovf_off);
-        if (hipMemsetAsync(a.ovf, 0, (size_t)cdiv(HW, AFF_BQ) * sizeof(int), s) != hipSuccess) return XMEM_ERR_LAUNCH;
-        a.cap = AFF_OPT_CAP;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)opt_lds()) != hipSuccess) return XMEM_ERR_LAUNCH;
-        hipLaunchKernelGGL((affinity_kernel<64, 1>), dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), opt_lds(), s, a);
+                           a.bound_part, pa.splits, HW, top_k, tau0, gcnt, ovf);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }
-    a.cap = pl.cap;
-    a.merge_splits = pl.splits;
-    if (a.ovf) {
-        // fallback of the optimistic pass: global candidate buffers, small LDS footprint (see MODE 3); its own, coarser
-        // split count keeps the scratch at <= max(512, query tiles) buffers (efficiency is irrelevant on this rare path)
+    {
+        const size_t lds = ((size_t)AFW_BQ * AFF_LDB + 3 * AFW_BQ) * sizeof(float) + (size_t)AFW_BQ * AFW_CAP * sizeof(u64);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
+        hipLaunchKernelGGL(affinity_wide_kernel, dim3(qt128, w.splits), dim3(512), lds, s, w);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    }
+    {
+        // safe kernel on the (normally zero) overflowed 64-query tiles: small grid, worst-case candidate buffers in global scratch
         const int qtiles = cdiv(HW, AFF_BQ);
-        int fs = 512 / qtiles; if (fs < 1) fs = 1; if (fs > pl.splits) fs = pl.splits;
-        a.chunk = 0;
-        a.tiles_per_split = cdiv(pl.sub_tiles, fs);
-        a.splits = cdiv(pl.sub_tiles, a.tiles_per_split);
-        if ((size_t)qtiles * a.splits * AFF_BQ * pl.cap * sizeof(u64) > wl.total - wl.spill_off) return XMEM_ERR_WORKSPACE;
+        AffPlan pl = aff_plan(tiles, HW, top_k, false);
+        a.tau_init = tau0; a.ovf = ovf;
+        a.limit = pl.limit; a.cap = pl.cap; a.tile_stride = 1; a.chunk = 0; a.sub_tiles = tiles;
+        a.tiles_per_split = cdiv(tiles, wl.fsplits);
+        a.splits = cdiv(tiles, a.tiles_per_split);
+        a.merge_splits = a.splits;
         a.cand_spill = reinterpret_cast<u64*>(ws + wl.spill_off);
         const size_t lds3 = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float);
         hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(qtiles, a.splits), dim3(256), lds3, s, a);
-    } else {
-        auto kern = affinity_kernel<64, 2>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
-            return XMEM_ERR_LAUNCH;
-        hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), 0, s, gcand, gcnt, ovf, a.part_key, a.part_cnt,
+                           a.splits, HW, top_k, out_w, out_idx, out_sim);
     }
-    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    const size_t mlds = ((size_t)pl.splits * AFF_OUTCAP + 2) * sizeof(u64) + (size_t)2 * top_k * sizeof(float);
-    hipLaunchKernelGGL(affinity_merge_kernel, dim3(HW), dim3(64), mlds, s, a.part_key, a.part_cnt, pl.splits, HW, top_k,
-                       out_w, out_idx, out_sim);
     return xmem_check_launch();
+}
+
+extern "C" int xmem_affinity_topk(const xmem_key_segment* segs, int n_seg, const float* qk, const float* qe, int Ck, int HW,
+                                  int top_k, float* out_w, int32_t* out_idx, float* out_sim,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return xmem_affinity_topk_hinted(segs, n_seg, qk, qe, Ck, HW, top_k, nullptr, out_w, out_idx, out_sim, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ Same attributes and method names as the reference ``MemoryManager`` (``match_mem
 Tensors handed in by ``InferenceCore`` are row-major: key ``[HW, C_k]``, shrinkage ``[HW]``, selection
 ``[HW, C_k]``, value ``[K, HW, C_v]``; hidden state is NHWC ``[K, h, w, C_h]``.
 """
+import os
 import warnings
 
 import torch
@@ -42,6 +43,10 @@ class MemoryManager:
         if self.enable_long_term:
             self.long_mem = KeyValueMemoryStore(count_usage=self.enable_long_term_usage)
         self.reset_config = True
+        # per object group: (top-k indices, segment sizes, grid width) of the previous match_memory call - handed to the next
+        # call as a bound hint (XMEM_AFFINITY_HINT=0 disables; outputs are identical either way)
+        self._aff_hint = {}
+        self.use_affinity_hint = os.environ.get('XMEM_AFFINITY_HINT', '1') != '0'
 
     def _read_lt(self, config):
         self.max_mt_frames = config['max_mid_term_frames']
@@ -83,7 +88,14 @@ class MemoryManager:
                 vs = st.get_v_size(gi)
                 start = st.size - vs
                 segs.append((st.key_rows(start), st.shrinkage_rows(start)))
-            w, idx, _ = ops.affinity_topk(segs, qk, qe, self.top_k)
+            # the previous frame's top-k indices of this group bound the k-th similarity of this frame from below (a hint only:
+            # the result does not depend on it, see xmem_affinity_topk_hinted)
+            sizes = [(k.shape[0] if k is not None else 0) for k, _ in segs]
+            hint = self._aff_hint.get(gi) if self.use_affinity_hint else None
+            if hint is not None and (hint[0].shape[0] != qk.shape[0] or len(hint[1]) != len(sizes)):
+                hint = None
+            w, idx, _ = ops.affinity_topk(segs, qk, qe, self.top_k, hint=hint)
+            self._aff_hint[gi] = (idx, sizes, self.W if self.W else 0)
             if gi == 0 and self.enable_long_term and not disable_usage_updates:
                 # usage from the first group only (it sees every key), memory_manager.py:93-97,133-141,150-155
                 first = 0

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_ptr
+from ._lib import AffinityHint, ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_ptr
 
 _workspaces = {}
 _retired = []
@@ -402,32 +402,45 @@ def nchw_to_nhwc(x):
 # memory readout
 # ---------------------------------------------------------------------------------------------
 
-def affinity_topk(segments, qk, qe, top_k, want_sim=False):
-    """segments: list of (key [n,Ck], shrinkage [n] | None).  Returns w [HW,k], idx [HW,k] (int32), sim | None."""
+def affinity_topk(segments, qk, qe, top_k, want_sim=False, hint=None):
+    """segments: list of (key [n,Ck], shrinkage [n] | None).  Returns w [HW,k], idx [HW,k] (int32), sim | None.
+    hint: None or (idx [HW,k'] int32 of an earlier call on the same list of stores, its segment sizes, grid width) - only
+    tightens the internal lower bound of the k-th similarity (xmem_affinity_topk_hinted); results do not depend on it."""
     lib = load()
     HW, ck = qk.shape
-    segs = [(k, s) for (k, s) in segments if k is not None and k.shape[0] > 0]
-    n_total = sum(k.shape[0] for k, _ in segs)
+    segs = [(k, s) if (k is not None and k.shape[0] > 0) else (None, None) for (k, s) in segments]   # empty stores keep their slot
+    n_total = sum(k.shape[0] for k, _ in segs if k is not None)
     if n_total < top_k:
         raise RuntimeError(f'selected index k out of range: top_k={top_k} > {n_total} memory elements')
     arr = (KeySegment * max(len(segs), 1))()
     for i, (k, s) in enumerate(segs):
-        arr[i].key = k.data_ptr()
+        arr[i].key = k.data_ptr() if k is not None else None
         arr[i].shrinkage = s.data_ptr() if s is not None else None
-        arr[i].n = k.shape[0]
+        arr[i].n = k.shape[0] if k is not None else 0
     w = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device)
     idx = torch.empty((HW, top_k), dtype=torch.int32, device=qk.device)
     sim = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device) if want_sim else None
     need = lib.xmem_affinity_topk_workspace_bytes(n_total, HW, top_k)
     ws = workspace(need, qk.device, 'affinity')
+    h, hp = None, None
+    if hint is not None:
+        h_idx, h_sizes, h_gw = hint
+        if h_idx is not None and h_idx.is_cuda and tuple(h_idx.shape[:1]) == (HW,) and h_idx.dtype == torch.int32 \
+                and len(h_sizes) == len(segs) <= 4:
+            h = AffinityHint()
+            h.idx = h_idx.data_ptr(); h.top_k = h_idx.shape[1]; h.n_seg = len(h_sizes)
+            for i, n in enumerate(h_sizes):
+                h.seg_n[i] = int(n)
+            h.grid_w = int(h_gw or 0)
+            hp = C.byref(h)
     e0 = _tap_begin()
-    check(lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
-                                 ptr(ws), need, stream_ptr()))
+    check(lib.xmem_affinity_topk_hinted(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, hp, ptr(w), ptr(idx), ptr(sim),
+                                        ptr(ws), need, stream_ptr()))
     _tap_end('affinity', e0, 4.0 * ck * n_total * HW)
     if RECORD is not None:
         RECORD.append(('affinity', f'{n_total}x{HW}k{top_k}', 4.0 * ck * n_total * HW,
-                       lambda: lib.xmem_affinity_topk(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, ptr(w), ptr(idx), ptr(sim),
-                                                      ptr(ws), need, stream_ptr()), (segs, qk, qe, w, idx, sim, ws)))
+                       lambda: lib.xmem_affinity_topk_hinted(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, hp, ptr(w), ptr(idx),
+                                                             ptr(sim), ptr(ws), need, stream_ptr()), (segs, qk, qe, w, idx, sim, ws, h, hint)))
     return w, idx, sim
 
 
