@@ -38,7 +38,7 @@ class _SimTap:
 def test_memory_scripts_hip(tag):
     """The HIP memory against the reference-recorded readouts.  A query may deviate from the recording only through a
     top-k fork: its k-th and (k+1)-th similarities (taken from the oracle run next to it) are a near-tie, so the other
-    element may legitimately be picked.  Forks are budgeted at 0.5 % of the queries of a match and every one of them is
+    element may legitimately be picked.  Forks are budgeted at 0.5 % of the queries of a match (at least one) and every one of them is
     checked to BE such a near-tie; everything else must agree to fp32 round-off."""
     from xmem2_amd.memory_manager import MemoryManager
     g = load_golden('mem_' + tag)
@@ -77,7 +77,7 @@ def test_memory_scripts_hip(tag):
             per_q = err.amax(dim=(0, 1)).flatten()
             forked = per_q > 5e-5 * scale
             n_fork += int(forked.sum()); n_q += forked.numel()
-            assert float(forked.float().mean()) <= 0.005 and float(per_q.max()) < 0.1 * scale, \
+            assert int(forked.sum()) <= max(1, round(0.005 * forked.numel())) and float(per_q.max()) < 0.1 * scale, \
                 f'{tag} step {step}: {int(forked.sum())}/{forked.numel()} queries deviate, max err {float(per_q.max()):.3e} (scale {scale:.3e})'
             for q in torch.nonzero(forked).flatten().tolist():       # every fork must be a k-th / (k+1)-th near-tie in some group
                 gaps = []

@@ -24,7 +24,7 @@ def ws_views():
     ws = ops._workspaces[(str(qs[0][0].device), 'affinity')]
     a = lambda v, al=256: (v + al - 1) // al * al
     cnt_off = a(64 * HW * 88 * 8); bound_off = cnt_off + a(64 * HW * 4); tau_off = bound_off + a(64 * HW * 8 * 4)
-    ovf_off = tau_off + a(HW * 4); gcand_off = ovf_off + a(((HW + 63) // 64) * 4); gcnt_off = gcand_off + a(HW * 256 * 8)
+    ovf_off = tau_off + a(HW * 4); gcand_off = ovf_off + a(((HW + 63) // 64) * 4); gcnt_off = gcand_off + a(HW * 1024 * 8)
     return (ws[tau_off:tau_off + HW * 4].view(torch.float32), ws[ovf_off:ovf_off + ((HW + 63) // 64) * 4].view(torch.int32),
             ws[gcnt_off:gcnt_off + HW * 4].view(torch.int32))
 def timeit(fn, reps=20):
@@ -35,7 +35,8 @@ def timeit(fn, reps=20):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 prev = None
-for f, (qk, qe) in enumerate(qs):
+NF = int(os.environ.get('PROBE_FRAMES', '32'))
+for f, (qk, qe) in enumerate(qs[:NF]):
     for mode, hint in (('nohint', None), ('hint', (prev, sizes, 54) if prev is not None else None), ('hint-nonb', (prev, sizes, 0) if prev is not None else None)):
         if mode != 'nohint' and hint is None:
             continue

@@ -464,7 +464,7 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
 #define AFW_BQ 128
 #define AFW_WAVES 8
 #define AFW_CAP 80          // per (workgroup, query) LDS candidates
-#define AFW_GCAP 256        // per-query global candidate list (all splits)
+#define AFW_GCAP 1024       // per-query global candidate list (all splits)
 
 struct WideArgs {
     SegDev seg[XMEM_MAX_SEGMENTS];
@@ -616,6 +616,11 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
                     if (rr < segn && x > my_tau[i]) {
                         const int slot = atomicAdd(&cnt[q], 1);
                         if (slot < AFW_CAP) cand[(size_t)q * AFW_CAP + slot] = pack_key(x, base + rr);
+                        else {                                     // LDS list full: straight to the query's global list
+                            const int gs = atomicAdd(&p.gcnt[q0 + q], 1);
+                            if (gs < AFW_GCAP) p.gcand[(size_t)(q0 + q) * AFW_GCAP + gs] = pack_key(x, base + rr);
+                            else p.ovf[(q0 + q) >> 6] = 1;
+                        }
                     }
                 }
             }
@@ -628,13 +633,11 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
         if (qg >= p.HW) continue;
         int c = cnt[q];
         if (c == 0) continue;
-        bool over = c > AFW_CAP;
-        c = over ? AFW_CAP : c;
+        c = c > AFW_CAP ? AFW_CAP : c;                    // the excess went to the global list directly
         int gb = 0;
         if (lane == 0) gb = atomicAdd(&p.gcnt[qg], c);
         gb = __shfl(gb, 0, 64);
-        if (gb + c > AFW_GCAP) over = true;
-        if (over && lane == 0) p.ovf[qg >> 6] = 1;
+        if (gb + c > AFW_GCAP && lane == 0) p.ovf[qg >> 6] = 1;
         for (int s2 = lane; s2 < c && gb + s2 < AFW_GCAP; s2 += 64) p.gcand[(size_t)qg * AFW_GCAP + gb + s2] = cand[(size_t)q * AFW_CAP + s2];
     }
 }
@@ -746,46 +749,120 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
     if (lane == 0) p.tau0[q] = res;
 }
 
-// Merge for the wide select: 16 lanes per query (4 queries per wave).  Source: the query's global list, or - when its
-// 64-query tile overflowed - the per-split lists written by the safe kernel.  Rank by counting (keys are unique: the
-// index is part of the key), sorted top-k, softmax without max shift (memory_util.py:48-49).
-#define AFM_MAXT 384
+// Merge for the wide select.  Light queries (<= AFM_LIGHT candidates, the normal case): 16 lanes per query, four queries
+// per wave, rank by counting (keys are unique: the index is part of the key).  Heavy queries (flat image regions keep
+// hundreds of near-tied candidates; tiles redone by the safe kernel): one wave per query with the lane-maxima pre-filter.
+// Source: the query's global list, or - when its 64-query tile overflowed - the per-split lists of the safe kernel.
+// Output: sorted top-k, softmax without max shift (memory_util.py:48-49).
+#define AFM_LIGHT 160
+#define AFM_HEAVY 1408      // >= max(AFW_GCAP, 4 fallback splits x AFF_OUTCAP)
+__device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb) {
+    fb = ovf[q >> 6] != 0;
+    if (!fb) { const int t = gcnt[q]; return t > AFW_GCAP ? AFW_GCAP : t; }
+    int t = 0;
+    for (int s = 0; s < fsplits; ++s) t += part_cnt[(size_t)s * HW + q];
+    return t > AFM_HEAVY ? AFM_HEAVY : t;
+}
 __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __restrict__ gcand, const int* __restrict__ gcnt,
                                                                const int* __restrict__ ovf, const u64* __restrict__ part_key,
                                                                const int* __restrict__ part_cnt, int fsplits, int HW, int top_k,
                                                                float* __restrict__ out_w, int* __restrict__ out_idx,
                                                                float* __restrict__ out_sim) {
-    __shared__ __attribute__((aligned(16))) u64 s_keys[16][AFM_MAXT + 2];
+    __shared__ __attribute__((aligned(16))) u64 s_keys[16][AFM_LIGHT + 2];
+    __shared__ __attribute__((aligned(16))) u64 s_heavy[4][AFM_HEAVY + 2];
     __shared__ float s_v[16][AFF_MAX_TOPK];
     __shared__ int s_i[16][AFF_MAX_TOPK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int q = blockIdx.x * 16 + g;
+    float* sv = s_v[g]; int* si = s_i[g];
+    bool fb = false;
+    const int total = q < HW ? merge_count(gcnt, ovf, part_cnt, fsplits, HW, q, fb) : 0;
+    const bool light = q < HW && total <= AFM_LIGHT;
+    if (light) {
+        u64* keys = s_keys[g];
+        if (fb) {
+            int off = 0;
+            for (int s = 0; s < fsplits; ++s) {
+                const int c = part_cnt[(size_t)s * HW + q];
+                for (int e = l; e < c; e += 16) keys[off + e] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + e];
+                off += c;
+            }
+        } else {
+            for (int e = l; e < total; e += 16) keys[e] = gcand[(size_t)q * AFW_GCAP + e];
+        }
+        if (l == 0) keys[total] = 0ull;
+        __builtin_amdgcn_wave_barrier();              // the 16 lanes of a group are one quarter of a wave: LDS ops are in order
+        for (int e = l; e < total; e += 16) {
+            const u64 ke = keys[e];
+            int rk = 0;
+            for (int f = 0; f < total; f += 2) {
+                const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(keys + f);
+                rk += (int)(kf.x > ke) + (int)((f + 1 < total) && (kf.y > ke));
+            }
+            if (rk < top_k) { sv[rk] = key_val(ke); si[rk] = key_idx(ke); }
+        }
+    }
+    // heavy queries of this wave (its four 16-lane groups), one at a time on all 64 lanes
+    for (int j = 0; j < 4; ++j) {
+        const int tj = __shfl(total, j * 16, 64);
+        const int qj = blockIdx.x * 16 + wv * 4 + j;
+        if (qj >= HW || tj <= AFM_LIGHT) continue;
+        const bool fbj = __shfl((int)fb, j * 16, 64) != 0;
+        u64* keys = s_heavy[wv];
+        float* svj = s_v[wv * 4 + j]; int* sij = s_i[wv * 4 + j];
+        int T = 0;
+        if (fbj) {
+            for (int s = 0; s < fsplits && T < AFM_HEAVY; ++s) {
+                int c = part_cnt[(size_t)s * HW + qj];
+                if (T + c > AFM_HEAVY) c = AFM_HEAVY - T;
+                for (int e = lane; e < c; e += 64) keys[T + e] = part_key[((size_t)s * HW + qj) * AFF_OUTCAP + e];
+                T += c;
+            }
+        } else {
+            T = tj;
+            for (int e = lane; e < T; e += 64) keys[e] = gcand[(size_t)qj * AFW_GCAP + e];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pre-filter: the top_k-th largest of the 64 lane-local maxima is reached by >= top_k candidates
+        u64 lmax = 0ull;
+        for (int e = lane; e < T; e += 64) { const u64 k = keys[e]; lmax = k > lmax ? k : lmax; }
+        int rk0 = 0;
+        for (int jj = 0; jj < 64; ++jj) {
+            const unsigned lo = __shfl((unsigned)lmax, jj, 64), hi = __shfl((unsigned)(lmax >> 32), jj, 64);
+            const u64 o = ((u64)hi << 32) | lo;
+            rk0 += (o > lmax) || (o == lmax && jj < lane);
+        }
+        const unsigned long long selm = __ballot(rk0 == top_k - 1);
+        const int src = selm ? __ffsll((long long)selm) - 1 : 0;
+        const unsigned tlo = __shfl((unsigned)lmax, src, 64), thi = __shfl((unsigned)(lmax >> 32), src, 64);
+        const u64 thr = selm ? (((u64)thi << 32) | tlo) : 0ull;
+        int nk = 0;
+        for (int b0 = 0; b0 < T; b0 += 64) {                   // stable in-place compaction (pos <= e)
+            const int e = b0 + lane;
+            const u64 k = e < T ? keys[e] : 0ull;
+            const bool keep = e < T && k >= thr;
+            const unsigned long long m = __ballot(keep);
+            const int pos = nk + __popcll(m & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (keep) keys[pos] = k;
+            nk += __popcll(m);
+        }
+        T = nk;
+        if (lane == 0) keys[T] = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < T; e += 64) {
+            const u64 ke = keys[e];
+            int rk = 0;
+            for (int f = 0; f < T; f += 2) {
+                const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(keys + f);
+                rk += (int)(kf.x > ke) + (int)((f + 1 < T) && (kf.y > ke));
+            }
+            if (rk < top_k) { svj[rk] = key_val(ke); sij[rk] = key_idx(ke); }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     if (q >= HW) return;
-    u64* keys = s_keys[g]; float* sv = s_v[g]; int* si = s_i[g];
-    int total = 0;
-    if (ovf[q >> 6]) {
-        for (int s = 0; s < fsplits; ++s) {
-            int c = part_cnt[(size_t)s * HW + q];
-            if (total + c > AFM_MAXT) c = AFM_MAXT - total;
-            for (int e = l; e < c; e += 16) keys[total + e] = part_key[((size_t)s * HW + q) * AFF_OUTCAP + e];
-            total += c;
-        }
-    } else {
-        total = gcnt[q];
-        if (total > AFW_GCAP) total = AFW_GCAP;
-        for (int e = l; e < total; e += 16) keys[e] = gcand[(size_t)q * AFW_GCAP + e];
-    }
-    if (l == 0) keys[total] = 0ull;
-    __builtin_amdgcn_wave_barrier();                  // the 16 lanes of a group are one quarter of a wave: LDS ops are in order
-    for (int e = l; e < total; e += 16) {
-        const u64 ke = keys[e];
-        int rk = 0;
-        for (int f = 0; f < total; f += 2) {
-            const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(keys + f);
-            rk += (int)(kf.x > ke) + (int)((f + 1 < total) && (kf.y > ke));
-        }
-        if (rk < top_k) { sv[rk] = key_val(ke); si[rk] = key_idx(ke); }
-    }
     __builtin_amdgcn_wave_barrier();
     float s = 0.f;
     for (int r = l; r < top_k; r += 16) s += expf(sv[r]);
