@@ -526,8 +526,10 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
     const int t_begin = p.chunk ? 0 : split * p.tiles_per_split;
     const int t_end = p.chunk ? p.tiles_per_split : min(p.sub_tiles, t_begin + p.tiles_per_split);
 
+    // next tile's key rows: unconditional loads (row index clamped into the segment: rows past its end are excluded by the
+    // filter's row test, never by exec-masked branches around the loads)
     f32x4 an[8]; float msn = 1.f;
-    int n_segn = 0, n_base = 0, n_row0 = 0; bool n_active = false;
+    int n_segn = 1, n_base = 0, n_row0 = 0; bool n_active = false;
     auto issue_loads = [&](int tile) {
         bool off = tile >= t_end;
         if (p.chunk && !off) {
@@ -536,23 +538,19 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
             off = tile >= p.sub_tiles;
         }
         n_active = !off;
-        const float* key = nullptr; const float* shr = nullptr;
-        n_segn = 0; n_base = 0; n_row0 = 0;
-        if (!off) {
-            int s = 0;
+        if (off) return;                              // wave-uniform
+        int sg = 0;
 #pragma unroll
-            for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
-                if (i < p.n_seg && tile >= p.seg[i].tile0) s = i;
-            key = p.seg[s].key; shr = p.seg[s].shr; n_segn = p.seg[s].n; n_base = p.seg[s].base;
-            n_row0 = (tile - p.seg[s].tile0) * AFF_ROWS;
-        }
-        const int r = n_row0 + l31;
-        const bool ok = n_active && r < n_segn;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+            if (i < p.n_seg && tile >= p.seg[i].tile0) sg = i;
+        const float* key = p.seg[sg].key; const float* shr = p.seg[sg].shr;
+        n_segn = p.seg[sg].n; n_base = p.seg[sg].base;
+        n_row0 = (tile - p.seg[sg].tile0) * AFF_ROWS;
+        const int r = min(n_row0 + l31, n_segn - 1);
         const float* src = key + (size_t)r * CK + lh * 4;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) an[t] = ok ? *reinterpret_cast<const f32x4*>(src + t * 8) : zero;
-        msn = (ok && shr) ? shr[r] : 1.f;
+        for (int t = 0; t < 8; ++t) an[t] = *reinterpret_cast<const f32x4*>(src + t * 8);
+        msn = shr ? shr[r] : 1.f;
     };
 
     float my_tau[4], my_bs[4];
@@ -597,15 +595,19 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
         float msr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) msr[r] = __shfl(ms_mine, (r & 3) + 8 * (r >> 2) + 4 * lh, 64) * inv_sqrt;
-        const bool full = row0 + AFF_ROWS <= segn;
+        const bool full = row0 + AFF_ROWS <= segn;        // wave-uniform
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float best = -INFINITY;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float x = c[i][r] * msr[r];
-                best = fmaxf(best, (full || rr < segn) ? x : -INFINITY);
+                for (int r = 0; r < 16; ++r) best = fmaxf(best, c[i][r] * msr[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    best = fmaxf(best, rr < segn ? c[i][r] * msr[r] : -INFINITY);
+                }
             }
             if (best > my_tau[i]) {                    // rare: walk the 16 values of this lane
                 const int q = i * 32 + l31;
@@ -661,13 +663,12 @@ struct HintArgs {
 __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
     constexpr int CK = 64;
     __shared__ __attribute__((aligned(16))) float s_op[4][2 * CK];
-    __shared__ float s_val[4][HINT_MAXC];
-    __shared__ int s_idx[4][HINT_MAXC];
+    __shared__ __attribute__((aligned(16))) float s_val[4][HINT_MAXC];
+    __shared__ int s_tab[4][512];                    // open-addressing set of the candidate indices (duplicates -> -inf)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= p.HW) return;
-    float* op = s_op[wv]; float* val = s_val[wv]; int* ix = s_idx[wv];
-    // query operands (-e | 2ke) and b_sq
+    float* op = s_op[wv]; float* val = s_val[wv]; int* tab = s_tab[wv];
     float bs = 0.f;
     {
         const float k = p.qk[(size_t)q * CK + lane];
@@ -676,8 +677,10 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         bs = p.qe ? e * (k * k) : 0.f;
     }
     bs = wave_sum(bs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tab[lane + 64 * i] = -1;
     if (lane == 0) { p.gcnt[q] = 0; if ((q & 63) == 0) p.ovf[q >> 6] = 0; }
-    // candidate indices: this query and its grid neighbours in the hint, re-based from the old segment layout to the new one
+    // candidate lists: this query and its grid neighbours in the hint
     int nq[5]; int nn = 0;
     nq[nn++] = q;
     if (p.grid_w > 0) {
@@ -688,51 +691,53 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         if (q + p.grid_w < p.HW) nq[nn++] = q + p.grid_w;
     }
     const int T = nn * p.hint_k;
-    for (int e = lane; e < T; e += 64) {
-        const int src = nq[e / p.hint_k], j = e - (e / p.hint_k) * p.hint_k;
-        int o = p.hint_idx[(size_t)src * p.hint_k + j];
-        int sgi = 0, ob = 0;
-#pragma unroll
-        for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i)
-            if (i + 1 < p.old_seg && o >= ob + p.old_n[i]) { ob += p.old_n[i]; sgi = i + 1; }
-        o -= ob;
-        sgi = p.new_of_old[sgi];
-        if (sgi >= p.n_seg) sgi = p.n_seg - 1;
-        if (o < 0) o = 0;
-        if (o >= p.seg[sgi].n) o = p.seg[sgi].n - 1;
-        ix[e] = p.seg[sgi].base + o;
-    }
+    const int T4 = (T + 3) & ~3;
     __builtin_amdgcn_wave_barrier();
-    // similarity lower estimates (duplicates -> -inf so that k DISTINCT elements back the bound)
-    for (int e = lane; e < T; e += 64) {
-        const int gi = ix[e];
-        bool dup = false;
-        for (int f = 0; f < e; ++f) dup |= (ix[f] == gi);
+    for (int e = lane; e < T4; e += 64) {
         float v = -INFINITY;
-        if (!dup) {
-            int sgi = 0;
+        if (e < T) {
+            const int li = e / p.hint_k;
+            int o = p.hint_idx[(size_t)nq[li] * p.hint_k + (e - li * p.hint_k)];
+            // re-base from the old segment layout to today's
+            int sgi = 0, ob = 0;
 #pragma unroll
-            for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
-                if (i < p.n_seg && gi >= p.seg[i].base) sgi = i;
-            const int o = gi - p.seg[sgi].base;
-            const float* row = p.seg[sgi].key + (size_t)o * CK;
-            float acc = 0.f, aacc = 0.f;
-#pragma unroll 4
-            for (int c4 = 0; c4 < CK; c4 += 4) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(row + c4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xv = x[j], xx = xv * xv;
-                    const float t1 = xx * op[c4 + j], t2 = xv * op[CK + c4 + j];
-                    acc += t1; acc += t2;
-                    aacc += fabsf(t1) + fabsf(t2);
-                }
+            for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i)
+                if (i + 1 < p.old_seg && o >= ob + p.old_n[i]) { ob += p.old_n[i]; sgi = i + 1; }
+            o -= ob;
+            sgi = p.new_of_old[sgi];
+            if (sgi >= p.n_seg) sgi = p.n_seg - 1;
+            if (o < 0) o = 0;
+            if (o >= p.seg[sgi].n) o = p.seg[sgi].n - 1;
+            const int gi = p.seg[sgi].base + o;
+            bool uniq = false;
+            unsigned h = ((unsigned)gi * 2654435761u) >> 23;
+            for (int probe = 0; probe < 512; ++probe) {
+                const int old = atomicCAS(&tab[h], -1, gi);
+                if (old == -1) { uniq = true; break; }
+                if (old == gi) break;
+                h = (h + 1) & 511u;
             }
-            const float ms = p.seg[sgi].shr ? p.seg[sgi].shr[o] : 1.f;
-            const float sc = fabsf(ms) * 0.125f;
-            const float est = (acc - bs) * (ms * 0.125f);
-            const float margin = (aacc + fabsf(bs)) * sc * 3.2e-5f + 1e-30f;      // > 2 * 130 * 2^-24 * sum|terms| (+ the two scalings)
-            v = est - margin;
+            if (uniq) {
+                const float* row = p.seg[sgi].key + (size_t)o * CK;
+                float acc = 0.f, aacc = 0.f;
+#pragma unroll 4
+                for (int c4 = 0; c4 < CK; c4 += 4) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(row + c4);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(op + c4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(op + CK + c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = x[j], xx = xv * xv;
+                        const float t1 = xx * lo[j], t2 = xv * hi[j];
+                        acc += t1; acc += t2;
+                        aacc += fabsf(t1) + fabsf(t2);
+                    }
+                }
+                const float ms = p.seg[sgi].shr ? p.seg[sgi].shr[o] : 1.f;
+                const float est = (acc - bs) * (ms * 0.125f);
+                const float margin = (aacc + fabsf(bs)) * (fabsf(ms) * 0.125f) * 3.2e-5f + 1e-30f;   // > 2 * 130 * 2^-24 * sum|terms|
+                v = est - margin;
+            }
         }
         val[e] = v;
     }
@@ -742,7 +747,11 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         const float ve = val[e];
         if (ve == -INFINITY) continue;
         int rk = 0;
-        for (int f = 0; f < T; ++f) { const float vf = val[f]; rk += (vf > ve) || (vf == ve && f < e); }
+        for (int f = 0; f < T4; f += 4) {
+            const f32x4 vf = *reinterpret_cast<const f32x4*>(val + f);
+            rk += (int)((vf.x > ve) || (vf.x == ve && f < e)) + (int)((vf.y > ve) || (vf.y == ve && f + 1 < e)) +
+                  (int)((vf.z > ve) || (vf.z == ve && f + 2 < e)) + (int)((vf.w > ve) || (vf.w == ve && f + 3 < e));
+        }
         if (rk == p.top_k - 1) res = ve;
     }
     res = wave_max(res);
