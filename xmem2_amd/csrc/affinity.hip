@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
 // hundreds of near-tied candidates; tiles redone by the safe kernel): one wave per query with the lane-maxima pre-filter.
 // Source: the query's global list, or - when its 64-query tile overflowed - the per-split lists of the safe kernel.
 // Output: sorted top-k, softmax without max shift (memory_util.py:48-49).
-#define AFM_LIGHT 160
+#define AFM_LIGHT 64
 #define AFM_HEAVY 1408      // >= max(AFW_GCAP, 4 fallback splits x AFF_OUTCAP)
 __device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb) {
     fb = ovf[q >> 6] != 0;
