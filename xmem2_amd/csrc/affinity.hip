@@ -104,25 +104,25 @@ __device__ __forceinline__ void rerank(u64* ck, int c, int top_k, float* tau_q, 
 // at the flag test, and with the big allocation they could not even START while another stream's kernels held LDS
 // (measured: 90 us per frame of pure scheduling stall under the pipelined key encoder).
 template <int CK, int MODE>
-__global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffArgs p) {
+__device__ __forceinline__ void affinity_body(const AffArgs& p, const int bx, const int by, const int spill_slot) {
     static_assert(CK == 64, "kernel is specialised for C_k = 64");
     constexpr bool BOUND = (MODE == 0);
     constexpr bool SAFE = (MODE >= 2);
     constexpr bool SPILL = (MODE == 3);
-    if (SAFE && p.ovf && p.ovf[blockIdx.x] == 0) return;
+    if (SAFE && p.ovf && p.ovf[bx] == 0) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bq = smem;                               // [64][132]
     float* bsq = Bq + AFF_BQ * AFF_LDB;             // [64]
     float* tau = bsq + AFF_BQ;                      // [64]
     int* cnt = reinterpret_cast<int*>(tau + AFF_BQ);  // [64]
     u64* cand = reinterpret_cast<u64*>(cnt + AFF_BQ + 4);  // [64][cap]   (select pass only); cnt[64..67]: flag + pad
-    if (SPILL) cand = p.cand_spill + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)AFF_BQ * p.cap);
+    if (SPILL) cand = p.cand_spill + (size_t)spill_slot * ((size_t)AFF_BQ * p.cap);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    const int q0 = blockIdx.x * AFF_BQ;
-    const int split = blockIdx.y;
+    const int q0 = bx * AFF_BQ;
+    const int split = by;
 
     // ---- stage the query operand:  k<64: -qe ; k>=64: 2*qk*qe ; b_sq = sum qe*qk^2 ----
     {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffA
                     const int slot = atomicAdd(&cnt[q], 1);
                     if (slot < p.cap) cand[(size_t)q * p.cap + slot] = pack_key(x, base + rr);
                     if (SAFE) { if (slot >= p.limit) *flag = 1; }
-                    else if (slot >= p.cap) p.ovf[blockIdx.x] = 1;   // optimistic buffers exhausted: redo this query tile safely
+                    else if (slot >= p.cap) p.ovf[bx] = 1;   // optimistic buffers exhausted: redo this query tile safely
                 }
             }
         }
@@ -349,6 +349,31 @@ __global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffA
         for (int s = lane; s < c; s += 64) p.part_key[o * AFF_OUTCAP + s] = cand[(size_t)q * p.cap + s];
         if (SPILL && lane == 0)                   // the fallback grid has fewer splits than the optimistic pass it replaces:
             for (int s2 = split + p.splits; s2 < p.merge_splits; s2 += p.splits) p.part_cnt[(size_t)s2 * p.HW + qg] = 0;
+    }
+}
+
+
+// MODE 0 / 1 / 2: one (query tile, split) per workgroup.  MODE 3 (the safe pass over tiles whose candidate lists overflowed,
+// normally none): a SMALL persistent grid - every workgroup lists the flagged tiles and takes (tile, split) pairs round-robin.
+// An unneeded launch therefore costs a handful of workgroups that read the flags and leave (a full-size grid of empty
+// workgroups queued for 20-60 us behind the other stream's kernels in the pipelined frame loop).
+#define AFF_FB_MAXTILES 2048
+template <int CK, int MODE>
+__global__ __launch_bounds__(256, (MODE == 2 ? 1 : 2)) void affinity_kernel(AffArgs p) {
+    if (MODE != 3) { affinity_body<CK, MODE>(p, blockIdx.x, blockIdx.y, 0); return; }
+    __shared__ int s_list[AFF_FB_MAXTILES];
+    __shared__ int s_n;
+    const int qtiles = (p.HW + AFF_BQ - 1) / AFF_BQ;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int t = 0; t < qtiles && n < AFF_FB_MAXTILES; ++t) if (p.ovf[t]) s_list[n++] = t;
+        s_n = n;
+    }
+    __syncthreads();
+    const int pairs = s_n * p.splits;
+    for (int it = blockIdx.x; it < pairs; it += gridDim.x) {
+        affinity_body<CK, MODE>(p, s_list[it / p.splits], it % p.splits, blockIdx.x);
+        __syncthreads();
     }
 }
 
@@ -764,7 +789,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
 // Source: the query's global list, or - when its 64-query tile overflowed - the per-split lists of the safe kernel.
 // Output: sorted top-k, softmax without max shift (memory_util.py:48-49).
 #define AFM_LIGHT 64
-#define AFM_HEAVY 1408      // >= max(AFW_GCAP, 4 fallback splits x AFF_OUTCAP)
+#define AFM_HEAVY 1408      // >= max(AFW_GCAP, 8 fallback splits x AFF_OUTCAP = 704)
 __device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb) {
     fb = ovf[q >> 6] != 0;
     if (!fb) { const int t = gcnt[q]; return t > AFW_GCAP ? AFW_GCAP : t; }
@@ -944,7 +969,8 @@ inline int bound_stride(int total_tiles) {
 
 struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
-inline int fallback_splits(int HW) { const int qt = cdiv(HW, AFF_BQ); int fs = 128 / qt; if (fs < 1) fs = 1; if (fs > 4) fs = 4; return fs; }
+#define AFF_FB_GRID 32      // persistent workgroups of the safe fallback pass
+inline int fallback_splits(int HW) { (void)HW; return 8; }
 WsLayout ws_layout(int HW) {
     WsLayout w;
     w.fsplits = fallback_splits(HW);
@@ -956,8 +982,8 @@ WsLayout ws_layout(int HW) {
     w.gcand_off = w.ovf_off + align_up((size_t)cdiv(HW, AFF_BQ) * sizeof(int), 256);
     w.gcnt_off = w.gcand_off + align_up((size_t)HW * AFW_GCAP * sizeof(u64), 256);
     w.spill_off = w.gcnt_off + align_up((size_t)HW * sizeof(int), 256);
-    // fallback buffers: one per workgroup of its grid (64-query tiles x fsplits), cap = 96 + 128
-    w.total = w.spill_off + (size_t)cdiv(HW, AFF_BQ) * w.fsplits * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64);
+    // fallback buffers: one per persistent workgroup, cap = 96 + 128
+    w.total = w.spill_off + (size_t)AFF_FB_GRID * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64);
     return w;
 }
 }  // namespace
@@ -1091,7 +1117,8 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         a.merge_splits = a.splits;
         a.cand_spill = reinterpret_cast<u64*>(ws + wl.spill_off);
         const size_t lds3 = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float);
-        hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(qtiles, a.splits), dim3(256), lds3, s, a);
+        if (qtiles > AFF_FB_MAXTILES) return XMEM_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(AFF_FB_GRID), dim3(256), lds3, s, a);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), 0, s, gcand, gcnt, ovf, a.part_key, a.part_cnt,
                            a.splits, HW, top_k, out_w, out_idx, out_sim);
