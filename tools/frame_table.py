@@ -9,10 +9,10 @@ from xmem2_amd.synth import synthetic_state_dict
 dev = torch.device('cuda:0')
 cfg = bench.b32_config()
 net = XMem(dict(cfg), None).to(dev).eval(); net.load_weights(synthetic_state_dict(0))
-frames, masks = bench.make_clip(4)
+frames, masks, _base, _nq = bench.make_clip(bench.WORKLOADS['b32'])
 fr, mk = torch.from_numpy(frames).to(dev), torch.from_numpy(masks).to(dev)
 core = InferenceCore(net, cfg); core.set_all_labels([1])
-for j in range(bench.MEM_FRAMES):
+for j in range(32):
     core.put_to_permanent_memory(fr[j], mk[j])
 core.step(fr[32], None, None)
 ops.RECORD = []

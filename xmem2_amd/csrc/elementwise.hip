@@ -157,10 +157,10 @@ extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* 
 
 // ---------------------------------------------------------------------------------------------
 // CBAM + residual:  out = g + SpatialGate(ChannelGate(g))
-//   1. channel_pool:   avg / max over the P pixels per (b, c)            -> pooled [B][2][C]
-//   2. channel_mlp:    sigmoid(mlp(avg) + mlp(max))                        -> cscale [B][C]
-//   3. compress:       per pixel max / mean over c of g*cscale             -> comp [B][P][2]
-//   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg
+//   1. channel_pool:   avg / max over the P pixels per (b, c)            -> pooled partials   (kernel 1: needs all pixels)
+//   2. channel_mlp:    cscale = sigmoid(mlp(avg) + mlp(max))
+//   3. compress:       per pixel max / mean over c of g*cscale
+//   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg             (2-4: kernel 2, per 8x8 pixel tile)
 // ---------------------------------------------------------------------------------------------
 #define CBAM_PSPLIT 16
 __global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __restrict__ partial, int P, int C) {
@@ -189,14 +189,33 @@ __global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __r
     }
 }
 
-__global__ void cbam_channel_mlp_kernel(const float* __restrict__ partial, const float* __restrict__ w1, const float* __restrict__ b1,
-                                        const float* __restrict__ w2, const float* __restrict__ b2,
-                                        float* __restrict__ cscale, int P, int C, int Cr) {
-    // one block per b; pooled [2][C] then hidden [2][Cr] in LDS
-    extern __shared__ float hid[];
-    float* pb = hid + 2 * Cr;
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+// Steps 2-4 in ONE kernel (the MLP / compress / gate kernels were latency-bound launches: 41 + 7 + 25 us for ~1 us of
+// arithmetic).  A workgroup owns an 8x8 pixel tile of one object and recomputes what it needs: the channel MLP from the
+// pooled partials (512 -> 32 -> 512: 64 K MACs), the channel-compressed map on the tile + its 3-pixel halo (the 7x7 gate
+// needs it), the gate for its 64 pixels and the gated residual.  Everything it re-reads is L2-resident (g is 3.3 MB).
+#define CBAM_T 8
+#define CBAM_HALO 3
+#define CBAM_TH (CBAM_T + 2 * CBAM_HALO)
+__global__ __launch_bounds__(256) void cbam_fused_kernel(const float* __restrict__ g, const float* __restrict__ partial,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         const float* __restrict__ sw, const float* __restrict__ sb,
+                                                         float* __restrict__ out, int H, int W, int C, int Cr) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pb = sm;                      // [2][C] pooled avg | max
+    float* cs = pb + 2 * C;              // [C] channel scale
+    float* hid = cs + C;                 // [2][Cr]
+    float* comp = hid + 2 * Cr;          // [TH][TH][2] (max, mean) of g*cs, 0 outside the image (the conv's zero padding)
+    float* sg = comp + CBAM_TH * CBAM_TH * 2;   // [T*T]
+    float* swl = sg + CBAM_T * CBAM_T;   // [98]
+    const int P = H * W;
+    const int tiles_x = (W + CBAM_T - 1) / CBAM_T;
+    const int ty0 = (blockIdx.x / tiles_x) * CBAM_T, tx0 = (blockIdx.x % tiles_x) * CBAM_T;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* gb = g + (size_t)b * P * C;
+    // ---- channel gate (same summation order as the stand-alone kernel had) ----
+    for (int c = tid; c < C; c += 256) {
         float s = 0.f, m = -INFINITY;
         for (int ps = 0; ps < CBAM_PSPLIT; ++ps) {
             s += partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 0) * C + c];
@@ -204,9 +223,9 @@ __global__ void cbam_channel_mlp_kernel(const float* __restrict__ partial, const
         }
         pb[c] = s / (float)P; pb[C + c] = m;
     }
+    if (tid < 98) swl[tid] = sw[tid];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int o = wave; o < 2 * Cr; o += nw) {
+    for (int o = wave; o < 2 * Cr; o += 4) {
         const int which = o / Cr, j = o - which * Cr;
         float s = 0.f;
         for (int c = lane; c < C; c += 64) s += pb[which * C + c] * w1[(size_t)j * C + c];
@@ -214,73 +233,59 @@ __global__ void cbam_channel_mlp_kernel(const float* __restrict__ partial, const
         if (lane == 0) hid[o] = fmaxf(s + b1[j], 0.f);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float sa = 0.f, sm = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        float sa = 0.f, smx = 0.f;
         for (int j = 0; j < Cr; ++j) {
             const float w = w2[(size_t)c * Cr + j];
-            sa += hid[j] * w; sm += hid[Cr + j] * w;
+            sa += hid[j] * w; smx += hid[Cr + j] * w;
         }
-        const float att = (sa + b2[c]) + (sm + b2[c]);
-        cscale[(size_t)b * C + c] = sigmoidf_(att);
+        cs[c] = sigmoidf_((sa + b2[c]) + (smx + b2[c]));
     }
-}
-
-__global__ void cbam_compress_kernel(const float* __restrict__ g, const float* __restrict__ cscale, float* __restrict__ comp,
-                                     int BP, int P, int C) {
-    // one wave per pixel
-    const int lane = threadIdx.x & 63;
-    const int wpb = blockDim.x >> 6;
-    for (int pix = blockIdx.x * wpb + (threadIdx.x >> 6); pix < BP; pix += gridDim.x * wpb) {
-        const int b = pix / P;
-        const float* gp = g + (size_t)pix * C;
-        const float* cs = cscale + (size_t)b * C;
+    __syncthreads();
+    // ---- channel compress on the tile + halo: one wave per pixel ----
+    for (int e = wave; e < CBAM_TH * CBAM_TH; e += 4) {
+        const int y = ty0 - CBAM_HALO + e / CBAM_TH, x = tx0 - CBAM_HALO + e % CBAM_TH;
         float s = 0.f, m = -INFINITY;
-        for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
-            const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c);
-            const float a0 = v.x * k.x, a1 = v.y * k.y, a2 = v.z * k.z, a3 = v.w * k.w;
-            s += (a0 + a1) + (a2 + a3);
-            m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        if (in) {
+            const float* gp = gb + ((size_t)y * W + x) * C;
+            for (int c = lane * 4; c < C; c += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
+                const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c);
+                const float a0 = v.x * k.x, a1 = v.y * k.y, a2 = v.z * k.z, a3 = v.w * k.w;
+                s += (a0 + a1) + (a2 + a3);
+                m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
+            }
+            s = wave_sum(s); m = wave_max(m);
         }
-        s = wave_sum(s); m = wave_max(m);
-        if (lane == 0) { comp[(size_t)pix * 2 + 0] = m; comp[(size_t)pix * 2 + 1] = s / (float)C; }
+        if (lane == 0) { comp[e * 2 + 0] = in ? m : 0.f; comp[e * 2 + 1] = in ? s / (float)C : 0.f; }
     }
-}
-
-__global__ void cbam_spatial_gate_kernel(const float* __restrict__ comp, const float* __restrict__ sw, const float* __restrict__ sb,
-                                         float* __restrict__ sgate, int B, int H, int W) {
-    const int total = B * H * W;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int x = e % W, y = (e / W) % H, b = e / (W * H);
+    __syncthreads();
+    // ---- 7x7 spatial gate for the tile's pixels ----
+    if (tid < CBAM_T * CBAM_T) {
+        const int py = tid / CBAM_T, px = tid % CBAM_T;
         float s = sb[0];
         for (int ch = 0; ch < 2; ++ch)
-            for (int dy = 0; dy < 7; ++dy) {
-                const int iy = y + dy - 3;
-                if ((unsigned)iy >= (unsigned)H) continue;
-                for (int dx = 0; dx < 7; ++dx) {
-                    const int ix = x + dx - 3;
-                    if ((unsigned)ix >= (unsigned)W) continue;
-                    s += comp[(((size_t)b * H + iy) * W + ix) * 2 + ch] * sw[(ch * 7 + dy) * 7 + dx];
-                }
-            }
-        sgate[e] = sigmoidf_(s);
+            for (int dy = 0; dy < 7; ++dy)
+                for (int dx = 0; dx < 7; ++dx)
+                    s += comp[((py + dy) * CBAM_TH + (px + dx)) * 2 + ch] * swl[(ch * 7 + dy) * 7 + dx];
+        sg[tid] = sigmoidf_(s);
     }
-}
-
-__global__ void cbam_apply_kernel(const float* __restrict__ g, const float* __restrict__ cscale, const float* __restrict__ sgate,
-                                  float* __restrict__ out, int BP, int P, int C4) {
-    const size_t total = (size_t)BP * C4;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(e % C4);
-        const int pix = (int)(e / C4);
-        const int b = pix / P;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(g + (size_t)pix * C4 * 4 + c4 * 4);
-        const f32x4 k = *reinterpret_cast<const f32x4*>(cscale + (size_t)b * C4 * 4 + c4 * 4);
-        const float sg = sgate[pix];
+    __syncthreads();
+    // ---- out = g + (g * cs) * sg ----
+    const int C4 = C >> 2;
+    for (int e = tid; e < CBAM_T * CBAM_T * C4; e += 256) {
+        const int c4 = e % C4, pp = e / C4;
+        const int y = ty0 + pp / CBAM_T, x = tx0 + pp % CBAM_T;
+        if (y >= H || x >= W) continue;
+        const size_t off = ((size_t)b * P + (size_t)y * W + x) * C + c4 * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(g + off);
+        const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c4 * 4);
+        const float gsc = sg[pp];
         f32x4 o;
-        o.x = v.x + (v.x * k.x) * sg; o.y = v.y + (v.y * k.y) * sg;
-        o.z = v.z + (v.z * k.z) * sg; o.w = v.w + (v.w * k.w) * sg;
-        *reinterpret_cast<f32x4*>(out + (size_t)pix * C4 * 4 + c4 * 4) = o;
+        o.x = v.x + (v.x * k.x) * gsc; o.y = v.y + (v.y * k.y) * gsc;
+        o.z = v.z + (v.z * k.z) * gsc; o.w = v.w + (v.w * k.w) * gsc;
+        *reinterpret_cast<f32x4*>(out + off) = o;
     }
 }
 
@@ -304,17 +309,17 @@ extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int 
     float* sgate = (float*)ws;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(cdiv(C, 64), B, CBAM_PSPLIT), dim3(256), 0, s, g, pooled, P, C);
-    hipLaunchKernelGGL(cbam_channel_mlp_kernel, dim3(B), dim3(512), (2 * Cr + 2 * C) * sizeof(float), s, pooled, w1, b1, w2, b2, cscale, P, C, Cr);
-    hipLaunchKernelGGL(cbam_compress_kernel, dim3(grid_for((size_t)B * P, 4)), dim3(256), 0, s, g, cscale, comp, B * P, P, C);
-    hipLaunchKernelGGL(cbam_spatial_gate_kernel, dim3(grid_for((size_t)B * P)), dim3(256), 0, s, comp, sw, sb, sgate, B, H, W);
-    hipLaunchKernelGGL(cbam_apply_kernel, dim3(grid_for((size_t)B * P * (C / 4))), dim3(256), 0, s, g, cscale, sgate, out, B * P, P, C / 4);
+    (void)cscale; (void)comp; (void)sgate;
+    const int tiles = cdiv(H, CBAM_T) * cdiv(W, CBAM_T);
+    const size_t lds = ((size_t)3 * C + 2 * Cr + CBAM_TH * CBAM_TH * 2 + CBAM_T * CBAM_T + 98) * sizeof(float);
+    hipLaunchKernelGGL(cbam_fused_kernel, dim3(tiles, B), dim3(256), lds, s, g, pooled, w1, b1, w2, b2, sw, sb, out, H, W, C, Cr);
     return xmem_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------
 // GRU-like gate, add3
 // ---------------------------------------------------------------------------------------------
-__global__ void gru_gate_kernel(const float* __restrict__ values, const float* __restrict__ h, float* __restrict__ nh,
+__global__ void gru_gate_kernel(const float* __restrict__ values, const float* h, float* nh,      // nh may alias h (in-place state update)
                                 size_t BP, int Ch) {
     const size_t total = BP * Ch;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {

@@ -40,6 +40,7 @@ class InferenceCore:
         self._pfq = collections.deque()      # prefetched frames in the order step() will consume them
         self._group_free = {}                # buffer group -> event after which the side stream may overwrite it
         self._group_parity = {}
+        self._uid = id(self)                 # owner token of this core's captured decoder stages (they update ITS hidden state in place)
         # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
         if getattr(network, 'device', None) is not None and network.device.type == 'cuda':
             with torch.cuda.device(network.device):
@@ -69,7 +70,7 @@ class InferenceCore:
         self.all_labels = all_labels
 
     # ---- helpers ---------------------------------------------------------------------------------
-    def _pack(self, image):
+    def _pack(self, image, out=None):
         """3 x H x W float (the reference's normalised frame, inference_core.py:73-74) or - ingest on the device,
         SURVEY 8f rank 2 - the decoded H x W x 3 uint8 frame, normalised here as video_reader.py:61-76 does."""
         u8 = image.dtype == torch.uint8 and image.dim() == 3 and image.shape[2] == 3
@@ -79,10 +80,10 @@ class InferenceCore:
         lw, uw, lh, uh = pad_amounts(H, W, 16)
         self.pad = (lw, uw, lh, uh)
         if u8:
-            return ops.pack_image_u8(image, H + lh + uh, W + lw + uw, lh, lw), (H, W), (H + lh + uh, W + lw + uw)
+            return ops.pack_image_u8(image, H + lh + uh, W + lw + uw, lh, lw, out=out), (H, W), (H + lh + uh, W + lw + uw)
         if image.dtype != torch.float32:
             image = image.float()
-        return ops.pack_image(image, H + lh + uh, W + lw + uw, lh, lw), (H, W), (H + lh + uh, W + lw + uw)
+        return ops.pack_image(image, H + lh + uh, W + lw + uw, lh, lw, out=out), (H, W), (H + lh + uh, W + lw + uw)
 
     def _pad_mask(self, mask, hw, hw_p):
         mask = mask.to(dtype=torch.float32)
@@ -145,9 +146,12 @@ class InferenceCore:
         saved_pad = getattr(self, 'pad', None)
         with torch.cuda.stream(self._side):
             devs = [im.to(net.device, non_blocking=True) if not im.is_cuda else im for im in images]
-            packed = [self._pack(d) for d in devs]
+            u8 = devs[0].dtype == torch.uint8
+            H0, W0 = (devs[0].shape[0], devs[0].shape[1]) if u8 else devs[0].shape[-2:]
+            lw_, uw_, lh_, uh_ = pad_amounts(H0, W0, 16)
+            image4 = torch.empty((B, H0 + lh_ + uh_, W0 + lw_ + uw_, 4), dtype=torch.float32, device=net.device)
+            packed = [self._pack(d, out=image4[i:i + 1]) for i, d in enumerate(devs)]     # straight into the batched buffer
             pad = self.pad
-            image4 = packed[0][0] if B == 1 else torch.cat([q[0] for q in packed], 0)
             outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=True, slot=gid, inline_skips=True)
             ev = torch.cuda.Event()
             ev.record(self._side)
@@ -216,12 +220,13 @@ class InferenceCore:
         if need_segment:
             hidden = mem.get_hidden()
             K = hidden.shape[0]
-            cat16 = net.new_decoder_input(K, h, w, f16.device, slot=slot)
+            cat16 = net.new_decoder_input(K, h, w, f16.device, slot=slot, owner=self._uid, h_out=is_normal_update,
+                                          has_skips=skips is not None)
             ld = cat16.shape[3]
             mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024,
                                   disable_usage_updates=disable_memory_updates)
             new_hidden, prob, prob_padded = net.segment_nhwc(f16, f8, f4, cat16, hidden, hw, (self.pad[2], self.pad[0]),
-                                                             h_out=is_normal_update, skips=skips, slot=slot)
+                                                             h_out=is_normal_update, skips=skips, slot=slot, owner=self._uid)
             if is_normal_update:
                 mem.set_hidden(new_hidden)
 

@@ -36,6 +36,7 @@ class XMem:
         # launch-bound stages (61 convolutions + ~40 small kernels per frame) are replayed as HIP graphs
         self.use_graphs = os.environ.get('XMEM_HIP_GRAPHS', '1') != '0'
         self._stages = {}
+        self._zeros = {}
         # the decoder's skip convolutions depend only on f8 / f4: inside the captured key-encoder graph they run on a
         # forked stream next to the small-grid layer2 / layer3 kernels.  Measured neutral on MI355X (A/B on one box:
         # 272 vs 273 fps), so it is off by default (XMEM_OVERLAP=1 enables it).
@@ -413,35 +414,57 @@ class XMem:
             hidden = ops.gru_gate(values, hidden)
         return value, hidden
 
-    def new_decoder_input(self, K, h, w, device, slot=0):
+    def new_decoder_input(self, K, h, w, device, slot=0, owner=0, h_out=None, has_skips=None):
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
-        Once the decoder stage is captured this is its static input buffer (no copy before the replay)."""
+        Once the matching decoder stage is captured this is its static input buffer (no copy before the replay)."""
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
         if self.use_graphs and not ops.eager_only():
             for k, st in self._stages.items():
-                if k[0] == 'segment' and k[1][-1] == slot and tuple(st[1][3].shape) == shape:
-                    return st[1][3]
+                if k[0] != 'segment' or k[1][-2] != slot or k[1][-1] != owner or tuple(st[1][3].shape) != shape:
+                    continue
+                if (h_out is not None and k[1][2] != bool(h_out)) or (has_skips is not None and k[1][3] != bool(has_skips)):
+                    continue
+                return st[1][3]
         return torch.empty(shape, dtype=torch.float32, device=device)
 
-    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True, skips=None, slot=0):
-        """Decoder + soft aggregation.  cat16 holds the memory readout at channels [1024,1024+Cv).
-        Returns new_hidden|None, prob [K+1,H,W] (unpadded), prob_padded [K+1,Hp,Wp]."""
-        self._need_weights()
-        if skips is not None:
-            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot),
-                                  [f16, f8, f4, cat16, hidden, skips[0], skips[1]],
-                                  lambda a, b, c, d, e, s8, s4: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out, (s8, s4)),
-                                  alias=(0, 1, 2, 5, 6) if self._is_stage_output(f16) else ())
-        else:
-            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), False, slot), [f16, f8, f4, cat16, hidden],
-                                  lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, out_hw, pad_tl, h_out),
-                                  alias=(0, 1, 2) if self._is_stage_output(f16) else ())
-        if self.use_graphs and not ops.eager_only():
-            new_hidden, prob, prob_padded = out              # hidden / prob outlive the stage's static buffers
-            return (new_hidden.clone() if new_hidden is not None else None), prob.clone(), prob_padded
-        return out
+    def _zero_scratch(self, shape, device):
+        """Persistent zero-initialised buffer (allocated outside any capture): kernels overwrite only its data channels, the
+        padding channels stay zero - no per-frame fill kernel."""
+        key = (tuple(shape), str(device))
+        buf = self._zeros.get(key)
+        if buf is None:
+            buf = torch.zeros(shape, dtype=torch.float32, device=device)
+            self._zeros[key] = buf
+        return buf
 
-    def _segment_eager(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out, skips=None):
+    def segment_nhwc(self, f16, f8, f4, cat16, hidden, out_hw, pad_tl, h_out=True, skips=None, slot=0, owner=0):
+        """Decoder + soft aggregation.  cat16 holds the memory readout at channels [1024,1024+Cv).
+        Returns new_hidden|None, prob [K+1,H,W] (unpadded), prob_padded [K+1,Hp,Wp].
+        The hidden state is updated IN PLACE (`new_hidden is hidden` when h_out): the captured stage reads and writes the
+        caller's state tensor (`owner` keys the stage so that two cores sharing one network never share a state buffer)."""
+        self._need_weights()
+        K, h, w, _ = cat16.shape
+        g4d = None
+        if h_out and self.hidden_dim > 0:
+            c4 = self._w['decoder.pred'].cin
+            g4d = self._zero_scratch((K, h, w, _pad4(c4 + 1)), cat16.device)
+        if skips is not None:
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot, owner),
+                                  [f16, f8, f4, cat16, hidden, skips[0], skips[1]],
+                                  lambda a, b, c, d, e, s8, s4: self._segment_eager(a, b, c, d, e, h_out, (s8, s4), g4d),
+                                  alias=(0, 1, 2, 4, 5, 6) if self._is_stage_output(f16) else (4,))
+        else:
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), False, slot, owner),
+                                  [f16, f8, f4, cat16, hidden],
+                                  lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, h_out, None, g4d),
+                                  alias=(0, 1, 2, 4) if self._is_stage_output(f16) else (4,))
+        new_hidden, logits = out
+        # soft aggregation outside the captured stage: prob / prob_padded are fresh tensors the caller may keep (no clone)
+        H, Wd = out_hw
+        prob, prob_padded = ops.logits_to_prob(logits.view(K, 4 * h, 4 * w), H, Wd, pad_tl[0], pad_tl[1])
+        return new_hidden, prob, prob_padded
+
+    def _segment_eager(self, f16, f8, f4, cat16, hidden, h_out, skips=None, g4d=None):
         W = self._w
         K, h, w, _ = cat16.shape
         hd = self.hidden_dim
@@ -458,7 +481,8 @@ class XMem:
         new_hidden = None
         if h_out and hd > 0:
             c4 = g4.shape[3]
-            g4d = torch.zeros((K, h, w, _pad4(c4 + 1)), dtype=torch.float32, device=g4.device)
+            if g4d is None:
+                g4d = self._zero_scratch((K, h, w, _pad4(c4 + 1)), g4.device)
             ops.area_downsample(g4, 4, out=g4d, out_ld=g4d.shape[3])
             ops.area_downsample(logits, 4, out=g4d, out_ld=g4d.shape[3], out_off=c4)
             g8d = ops.area_downsample(g8, 2)
@@ -468,10 +492,8 @@ class XMem:
             ops.conv2d(g4d, W['decoder.hidden_update.g4_conv'], res=t, out=cat, out_ld=cat.shape[3])
             ops.copy_channels(hidden, cat, t.shape[3])
             values = ops.conv2d(cat, W['decoder.hidden_update.transform'])
-            new_hidden = ops.gru_gate(values, hidden)
-        H, Wd = out_hw
-        prob, prob_padded = ops.logits_to_prob(logits.view(K, 4 * h, 4 * w), H, Wd, pad_tl[0], pad_tl[1])
-        return new_hidden, prob, prob_padded
+            new_hidden = ops.gru_gate(values, hidden, out=hidden)          # in place: the state tensor itself advances
+        return new_hidden, logits
 
     # ---- reference-shaped wrappers (NCHW in / out) ----------------------------------------------
     @staticmethod
@@ -521,7 +543,11 @@ class XMem:
         hidden = self._as_nhwc(hidden_state[0]) if hidden_state is not None else None
         cat16 = self.new_decoder_input(K, h, w, ro.device)
         ops.copy_channels(ro, cat16, 1024)
+        if hidden is not None and hidden_state is not None and hidden.data_ptr() == hidden_state.data_ptr():
+            hidden = hidden.clone()                     # the reference-shaped call must not edit the caller's tensor
         new_hidden, _, prob = self.segment_nhwc(f16, f8, f4, cat16, hidden, (16 * h, 16 * w), (0, 0), h_out)
+        if new_hidden is not None:
+            new_hidden = new_hidden.clone()             # the stage's state buffer is reused by the next call
         prob = prob.unsqueeze(0)
         if strip_bg:
             prob = prob[:, 1:]

@@ -286,19 +286,22 @@ def cbam_residual(g, p):
     return out
 
 
-def gru_gate(values, h):
+def gru_gate(values, h, out=None):
+    """out may be h itself (in-place update of the hidden state)."""
     B, H, W, Ch = h.shape
-    out = torch.empty_like(h)
+    if out is None:
+        out = torch.empty_like(h)
     check(load().xmem_gru_gate(ptr(values), ptr(h), ptr(out), B, H * W, Ch, stream_ptr()))
     return out
 
 
-def pack_image(img, Hp, Wp, lh, lw):
-    """img [3,H,W] -> [1,Hp,Wp,4] zero padded NHWC."""
+def pack_image(img, Hp, Wp, lh, lw, out=None):
+    """img [3,H,W] -> [1,Hp,Wp,4] zero padded NHWC (into `out` when given: one frame of a batched buffer)."""
     _req(img, 'image')
     if not img.is_contiguous():
         img = img.contiguous()
-    out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img.device)
+    if out is None:
+        out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img.device)
     check(load().xmem_pack_image(ptr(img), ptr(out), img.shape[1], img.shape[2], Hp, Wp, lh, lw, stream_ptr()))
     return out
 
@@ -307,13 +310,14 @@ IM_MEAN = (0.485, 0.456, 0.406)      # dataset/range_transform.py:5-8
 IM_STD = (0.229, 0.224, 0.225)
 
 
-def pack_image_u8(img, Hp, Wp, lh, lw, mean=IM_MEAN, std=IM_STD):
+def pack_image_u8(img, Hp, Wp, lh, lw, mean=IM_MEAN, std=IM_STD, out=None):
     """decoded frame uint8 [H,W,3] -> normalised, zero padded [1,Hp,Wp,4] (ToTensor + Normalize + pad in one kernel)."""
     if not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
         raise RuntimeError('pack_image_u8: expected a CUDA (HIP) uint8 tensor of shape [H, W, 3]')
     if not img.is_contiguous():
         img = img.contiguous()
-    out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img.device)
+    if out is None:
+        out = torch.empty((1, Hp, Wp, 4), dtype=torch.float32, device=img.device)
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
     check(load().xmem_pack_image_u8(ptr(img), ptr(out), img.shape[0], img.shape[1], Hp, Wp, lh, lw, m3, s3, stream_ptr()))
     return out
