@@ -160,7 +160,7 @@ extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* 
 //   1. channel_pool:   avg / max over the P pixels per (b, c)            -> pooled partials   (kernel 1: needs all pixels)
 //   2. channel_mlp:    cscale = sigmoid(mlp(avg) + mlp(max))
 //   3. compress:       per pixel max / mean over c of g*cscale
-//   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg             (2-4: kernel 2, per 8x8 pixel tile)
+//   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg             (2-3: kernel 2, 4: kernel 3; 16 pixels per workgroup)
 // ---------------------------------------------------------------------------------------------
 #define CBAM_PSPLIT 16
 __global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __restrict__ partial, int P, int C) {
@@ -189,32 +189,16 @@ __global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __r
     }
 }
 
-// Steps 2-4 in ONE kernel (the MLP / compress / gate kernels were latency-bound launches: 41 + 7 + 25 us for ~1 us of
-// arithmetic).  A workgroup owns an 8x8 pixel tile of one object and recomputes what it needs: the channel MLP from the
-// pooled partials (512 -> 32 -> 512: 64 K MACs), the channel-compressed map on the tile + its 3-pixel halo (the 7x7 gate
-// needs it), the gate for its 64 pixels and the gated residual.  Everything it re-reads is L2-resident (g is 3.3 MB).
-#define CBAM_T 8
-#define CBAM_HALO 3
-#define CBAM_TH (CBAM_T + 2 * CBAM_HALO)
-__global__ __launch_bounds__(256) void cbam_fused_kernel(const float* __restrict__ g, const float* __restrict__ partial,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1,
-                                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         const float* __restrict__ sw, const float* __restrict__ sb,
-                                                         float* __restrict__ out, int H, int W, int C, int Cr) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* pb = sm;                      // [2][C] pooled avg | max
-    float* cs = pb + 2 * C;              // [C] channel scale
-    float* hid = cs + C;                 // [2][Cr]
-    float* comp = hid + 2 * Cr;          // [TH][TH][2] (max, mean) of g*cs, 0 outside the image (the conv's zero padding)
-    float* sg = comp + CBAM_TH * CBAM_TH * 2;   // [T*T]
-    float* swl = sg + CBAM_T * CBAM_T;   // [98]
-    const int P = H * W;
-    const int tiles_x = (W + CBAM_T - 1) / CBAM_T;
-    const int ty0 = (blockIdx.x / tiles_x) * CBAM_T, tx0 = (blockIdx.x % tiles_x) * CBAM_T;
-    const int b = blockIdx.y;
+// Steps 2-4 in two kernels of many small workgroups (16 pixels each): every workgroup recomputes the channel MLP from the
+// pooled partials (512 -> 32 -> 512: 64 K MACs, L2-resident operands) instead of waiting for a one-workgroup MLP launch
+// (41 us of latency for ~1 us of arithmetic), then (a) compresses its pixels over the channels; (b) after the compressed map
+// is complete, takes the 7x7 gate of its pixels and applies the gated residual.
+#define CBAM_PIX 16
+__device__ __forceinline__ void cbam_channel_scale(const float* __restrict__ partial, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2,
+                                                   const float* __restrict__ b2, int b, int P, int C, int Cr,
+                                                   float* pb, float* hid, float* cs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* gb = g + (size_t)b * P * C;
-    // ---- channel gate (same summation order as the stand-alone kernel had) ----
     for (int c = tid; c < C; c += 256) {
         float s = 0.f, m = -INFINITY;
         for (int ps = 0; ps < CBAM_PSPLIT; ++ps) {
@@ -223,7 +207,6 @@ __global__ __launch_bounds__(256) void cbam_fused_kernel(const float* __restrict
         }
         pb[c] = s / (float)P; pb[C + c] = m;
     }
-    if (tid < 98) swl[tid] = sw[tid];
     __syncthreads();
     for (int o = wave; o < 2 * Cr; o += 4) {
         const int which = o / Cr, j = o - which * Cr;
@@ -242,46 +225,70 @@ __global__ __launch_bounds__(256) void cbam_fused_kernel(const float* __restrict
         cs[c] = sigmoidf_((sa + b2[c]) + (smx + b2[c]));
     }
     __syncthreads();
-    // ---- channel compress on the tile + halo: one wave per pixel ----
-    for (int e = wave; e < CBAM_TH * CBAM_TH; e += 4) {
-        const int y = ty0 - CBAM_HALO + e / CBAM_TH, x = tx0 - CBAM_HALO + e % CBAM_TH;
+}
+
+__global__ __launch_bounds__(256) void cbam_compress_kernel(const float* __restrict__ g, const float* __restrict__ partial,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ cscale, float* __restrict__ comp, int P, int C, int Cr) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* pb = sm; float* cs = pb + 2 * C; float* hid = cs + C;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cbam_channel_scale(partial, w1, b1, w2, b2, b, P, C, Cr, pb, hid, cs);
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) cscale[(size_t)b * C + c] = cs[c];
+    for (int i = wave; i < CBAM_PIX; i += 4) {                   // one wave per pixel
+        const int pix = blockIdx.x * CBAM_PIX + i;
+        if (pix >= P) break;
+        const float* gp = g + ((size_t)b * P + pix) * C;
         float s = 0.f, m = -INFINITY;
-        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        if (in) {
-            const float* gp = gb + ((size_t)y * W + x) * C;
-            for (int c = lane * 4; c < C; c += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
-                const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c);
-                const float a0 = v.x * k.x, a1 = v.y * k.y, a2 = v.z * k.z, a3 = v.w * k.w;
-                s += (a0 + a1) + (a2 + a3);
-                m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
-            }
-            s = wave_sum(s); m = wave_max(m);
+        for (int c = lane * 4; c < C; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
+            const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c);
+            const float a0 = v.x * k.x, a1 = v.y * k.y, a2 = v.z * k.z, a3 = v.w * k.w;
+            s += (a0 + a1) + (a2 + a3);
+            m = fmaxf(fmaxf(m, fmaxf(a0, a1)), fmaxf(a2, a3));
         }
-        if (lane == 0) { comp[e * 2 + 0] = in ? m : 0.f; comp[e * 2 + 1] = in ? s / (float)C : 0.f; }
+        s = wave_sum(s); m = wave_max(m);
+        if (lane == 0) { comp[((size_t)b * P + pix) * 2 + 0] = m; comp[((size_t)b * P + pix) * 2 + 1] = s / (float)C; }
+    }
+}
+
+__global__ __launch_bounds__(256) void cbam_gate_apply_kernel(const float* __restrict__ g, const float* __restrict__ cscale,
+                                                              const float* __restrict__ comp, const float* __restrict__ sw,
+                                                              const float* __restrict__ sb, float* __restrict__ out,
+                                                              int H, int W, int C) {
+    __shared__ float sg[CBAM_PIX];
+    __shared__ float swl[98];
+    const int P = H * W, b = blockIdx.y, tid = threadIdx.x;
+    if (tid < 98) swl[tid] = sw[tid];
+    __syncthreads();
+    {   // 16 lanes per pixel over the 98 taps of the 7x7x2 gate
+        const int i = tid >> 4, l = tid & 15;
+        const int pix = blockIdx.x * CBAM_PIX + i;
+        float s = 0.f;
+        if (pix < P) {
+            const int y = pix / W, x = pix - y * W;
+            for (int t = l; t < 98; t += 16) {
+                const int ch = t / 49, r = t - ch * 49, dy = r / 7, dx = r - dy * 7;
+                const int iy = y + dy - 3, ix = x + dx - 3;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    s += comp[(((size_t)b * H + iy) * W + ix) * 2 + ch] * swl[t];
+            }
+        }
+        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
+        if (l == 0) sg[i] = sigmoidf_(s + sb[0]);
     }
     __syncthreads();
-    // ---- 7x7 spatial gate for the tile's pixels ----
-    if (tid < CBAM_T * CBAM_T) {
-        const int py = tid / CBAM_T, px = tid % CBAM_T;
-        float s = sb[0];
-        for (int ch = 0; ch < 2; ++ch)
-            for (int dy = 0; dy < 7; ++dy)
-                for (int dx = 0; dx < 7; ++dx)
-                    s += comp[((py + dy) * CBAM_TH + (px + dx)) * 2 + ch] * swl[(ch * 7 + dy) * 7 + dx];
-        sg[tid] = sigmoidf_(s);
-    }
-    __syncthreads();
-    // ---- out = g + (g * cs) * sg ----
     const int C4 = C >> 2;
-    for (int e = tid; e < CBAM_T * CBAM_T * C4; e += 256) {
-        const int c4 = e % C4, pp = e / C4;
-        const int y = ty0 + pp / CBAM_T, x = tx0 + pp % CBAM_T;
-        if (y >= H || x >= W) continue;
-        const size_t off = ((size_t)b * P + (size_t)y * W + x) * C + c4 * 4;
+    for (int e = tid; e < CBAM_PIX * C4; e += 256) {
+        const int c4 = e % C4, i = e / C4;
+        const int pix = blockIdx.x * CBAM_PIX + i;
+        if (pix >= P) break;
+        const size_t off = ((size_t)b * P + pix) * C + c4 * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(g + off);
-        const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c4 * 4);
-        const float gsc = sg[pp];
+        const f32x4 k = *reinterpret_cast<const f32x4*>(cscale + (size_t)b * C + c4 * 4);
+        const float gsc = sg[i];
         f32x4 o;
         o.x = v.x + (v.x * k.x) * gsc; o.y = v.y + (v.y * k.y) * gsc;
         o.z = v.z + (v.z * k.z) * gsc; o.w = v.w + (v.w * k.w) * gsc;
@@ -309,10 +316,10 @@ extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int 
     float* sgate = (float*)ws;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(cdiv(C, 64), B, CBAM_PSPLIT), dim3(256), 0, s, g, pooled, P, C);
-    (void)cscale; (void)comp; (void)sgate;
-    const int tiles = cdiv(H, CBAM_T) * cdiv(W, CBAM_T);
-    const size_t lds = ((size_t)3 * C + 2 * Cr + CBAM_TH * CBAM_TH * 2 + CBAM_T * CBAM_T + 98) * sizeof(float);
-    hipLaunchKernelGGL(cbam_fused_kernel, dim3(tiles, B), dim3(256), lds, s, g, pooled, w1, b1, w2, b2, sw, sb, out, H, W, C, Cr);
+    (void)sgate;
+    const size_t lds = ((size_t)3 * C + 2 * Cr) * sizeof(float);
+    hipLaunchKernelGGL(cbam_compress_kernel, dim3(cdiv(P, CBAM_PIX), B), dim3(256), lds, s, g, pooled, w1, b1, w2, b2, cscale, comp, P, C, Cr);
+    hipLaunchKernelGGL(cbam_gate_apply_kernel, dim3(cdiv(P, CBAM_PIX), B), dim3(256), 0, s, g, cscale, comp, sw, sb, out, H, W, C);
     return xmem_check_launch();
 }
 

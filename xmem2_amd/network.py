@@ -226,7 +226,7 @@ class XMem:
             self._upload()
 
     # ---- HIP-graph staging ------------------------------------------------------------------------
-    def _run_stage(self, name, key, inputs, fn, alias=()):
+    def _run_stage(self, name, key, inputs, fn, alias=(), mutates=()):
         """Run `fn(*inputs)` eagerly, or capture it once per (name, shapes, flags) into a HIP graph with static
         input / output buffers and replay it.  Kernels are launched through ctypes on torch's current stream, which
         is the capturing stream inside torch.cuda.graph, so they are captured like any other launch."""
@@ -237,7 +237,9 @@ class XMem:
         if st is None:
             # inputs listed in `alias` are themselves stable buffers (outputs of another stage): use them in place
             static_in = [(t if i in alias else t.clone()) if t is not None else None for i, t in enumerate(inputs)]
-            fn(*static_in)                                  # warm-up: sizes every workspace before the capture
+            # warm-up: sizes every workspace before the capture.  Inputs the stage updates in place (`mutates`: the hidden
+            # state) are cloned for it, otherwise warm-up + first replay would advance the state twice.
+            fn(*[(t.clone() if (i in mutates and t is not None) else t) for i, t in enumerate(static_in)])
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -452,12 +454,12 @@ class XMem:
             out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot, owner),
                                   [f16, f8, f4, cat16, hidden, skips[0], skips[1]],
                                   lambda a, b, c, d, e, s8, s4: self._segment_eager(a, b, c, d, e, h_out, (s8, s4), g4d),
-                                  alias=(0, 1, 2, 4, 5, 6) if self._is_stage_output(f16) else (4,))
+                                  alias=(0, 1, 2, 4, 5, 6) if self._is_stage_output(f16) else (4,), mutates=(4,))
         else:
             out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), False, slot, owner),
                                   [f16, f8, f4, cat16, hidden],
                                   lambda a, b, c, d, e: self._segment_eager(a, b, c, d, e, h_out, None, g4d),
-                                  alias=(0, 1, 2, 4) if self._is_stage_output(f16) else (4,))
+                                  alias=(0, 1, 2, 4) if self._is_stage_output(f16) else (4,), mutates=(4,))
         new_hidden, logits = out
         # soft aggregation outside the captured stage: prob / prob_padded are fresh tensors the caller may keep (no clone)
         H, Wd = out_hw
