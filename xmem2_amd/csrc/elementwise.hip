@@ -198,29 +198,57 @@ __device__ __forceinline__ void cbam_channel_scale(const float* __restrict__ par
                                                    const float* __restrict__ b1, const float* __restrict__ w2,
                                                    const float* __restrict__ b2, int b, int P, int C, int Cr,
                                                    float* pb, float* hid, float* cs) {
+    // latency-bound: every phase issues all of its independent loads before reducing
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < C; c += 256) {
-        float s = 0.f, m = -INFINITY;
+        float sv[CBAM_PSPLIT], mv[CBAM_PSPLIT];
+#pragma unroll
         for (int ps = 0; ps < CBAM_PSPLIT; ++ps) {
-            s += partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 0) * C + c];
-            m = fmaxf(m, partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 1) * C + c]);
+            sv[ps] = partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 0) * C + c];
+            mv[ps] = partial[(((size_t)b * CBAM_PSPLIT + ps) * 2 + 1) * C + c];
         }
+        float s = 0.f, m = -INFINITY;
+#pragma unroll
+        for (int ps = 0; ps < CBAM_PSPLIT; ++ps) { s += sv[ps]; m = fmaxf(m, mv[ps]); }
         pb[c] = s / (float)P; pb[C + c] = m;
     }
     __syncthreads();
-    for (int o = wave; o < 2 * Cr; o += 4) {
-        const int which = o / Cr, j = o - which * Cr;
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += pb[which * C + c] * w1[(size_t)j * C + c];
-        s = wave_sum(s);
-        if (lane == 0) hid[o] = fmaxf(s + b1[j], 0.f);
+    // hidden layer: wave w owns units j = w, w+4, ... for BOTH pooled vectors (the weight row is loaded once); up to 8 units
+    // per wave are accumulated side by side so that their weight loads are all in flight together
+    for (int j0 = wave; j0 < Cr; j0 += 32) {
+        float acc0[8], acc1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc0[u] = 0.f; acc1[u] = 0.f; }
+        for (int c = lane; c < C; c += 64) {
+            const float p0 = pb[c], p1 = pb[C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 4 * u;
+                const float wv = j < Cr ? w1[(size_t)j * C + c] : 0.f;
+                acc0[u] += p0 * wv; acc1[u] += p1 * wv;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 4 * u;
+            const float s0 = wave_sum(acc0[u]), s1 = wave_sum(acc1[u]);
+            if (lane == 0 && j < Cr) { hid[j] = fmaxf(s0 + b1[j], 0.f); hid[Cr + j] = fmaxf(s1 + b1[j], 0.f); }
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float sa = 0.f, smx = 0.f;
-        for (int j = 0; j < Cr; ++j) {
-            const float w = w2[(size_t)c * Cr + j];
-            sa += hid[j] * w; smx += hid[Cr + j] * w;
+        const float* wr = w2 + (size_t)c * Cr;
+        if ((Cr & 3) == 0) {
+            for (int j = 0; j < Cr; j += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + j);
+                sa += hid[j] * w.x; smx += hid[Cr + j] * w.x;
+                sa += hid[j + 1] * w.y; smx += hid[Cr + j + 1] * w.y;
+                sa += hid[j + 2] * w.z; smx += hid[Cr + j + 2] * w.z;
+                sa += hid[j + 3] * w.w; smx += hid[Cr + j + 3] * w.w;
+            }
+        } else {
+            for (int j = 0; j < Cr; ++j) { sa += hid[j] * wr[j]; smx += hid[Cr + j] * wr[j]; }
         }
         cs[c] = sigmoidf_((sa + b2[c]) + (smx + b2[c]));
     }
