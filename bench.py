@@ -149,7 +149,7 @@ def run_gpu(args, device, rank, world):
     wl = WORKLOADS[args.workload]
     cfg = workload_config(wl)
     sd = synthetic_state_dict(0)
-    net = XMem(dict(cfg), None).to(device).eval()
+    net = XMem(dict(cfg, precision=args.precision), None).to(device).eval()
     net.load_weights(sd)
     frames, masks, base, n_query = make_clip(wl)
     fr = torch.from_numpy(frames).to(device)
@@ -285,7 +285,7 @@ def run_traced_child(args):
     tmp = tempfile.mkdtemp(prefix='xmem_trace_', dir=os.environ.get('TMPDIR', '/tmp'))
     cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', tmp, '--', sys.executable, os.path.abspath(__file__),
            '--steps', str(steps), '--warmup', str(args.warmup), '--workload', args.workload, '--key-batch', str(args.key_batch),
-           '--traced-child', '--no-cpu-baseline']
+           '--traced-child', '--no-cpu-baseline', '--precision', args.precision]
     if args.no_prefetch:
         cmd.append('--no-prefetch')
     env = dict(os.environ, TMPDIR=os.environ.get('TMPDIR', '/tmp'))
@@ -412,6 +412,9 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='b32', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline at its best thread count')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
+                    help='fp16 = the opt-in reduced-precision mode (Winograd-domain operands in fp16, fp32 accumulation; SURVEY 8f-4): '
+                         'reported under its own metric label, never the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefetch', action='store_true', help='do not pipeline the coming frames\' key encoder')
     ap.add_argument('--key-batch', type=int, default=4, help='frames per batched key-encoder hint (prefetch_keys)')
@@ -486,10 +489,12 @@ def main():
         aff_gf = aff['flop'] / nf / 1e9 if aff else alg['similarity']
         aff_tflops = (aff_gf / aff_ms) if aff_ms else None                     # GF / ms = TF/s
         line = {
-            'metric': BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})',
+            'metric': (BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})') +
+                      ('' if args.precision == 'fp32' else ' [REDUCED-PRECISION MODE fp16: not the headline metric]'),
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f16 Winograd-domain conv operands, f32 accumulate; everything else f32',
+            'data': 'synthetic',
             'config': {'workload': wl['desc'] + '; step()+argmax+uint8 mask to host per frame, conditioned synthetic weights',
                        'workload_key': args.workload, 'replica_streams': world, 'top_k': TOPK,
                        'frame_pipelining': (not args.no_prefetch), 'key_batch': (args.key_batch if not args.no_prefetch else 0),

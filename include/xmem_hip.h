@@ -67,11 +67,16 @@ typedef struct {
     int relu_in, relu_out;
     int plan_tile;      /* 0 = built-in heuristic; 1..6 = {128x128, 128x64, 64x64} x {BK 32, BK 64} (autotuner override);
                            7..12 = the same GEMM tiles inside the Winograd F(2x2,3x3) path (needs w_winograd);
-                           13..15 = fused Winograd GEMM + output transform, tiles {128x64, 64x64, 64x128} */
+                           13..15 = fused Winograd GEMM + output transform, tiles {128x64, 64x64, 64x128};
+                           16 = REDUCED PRECISION (opt-in mode only, never the default): Winograd path whose transformed
+                                operands are stored in fp16 and multiplied on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+                                (needs w_winograd_f16, Cin % 64 == 0) - the counterpart of the reference's
+                                torch.cuda.amp.autocast loop, inference/run_on_video.py:76 */
     int plan_splitk;    /* 0 = heuristic; >0 = number of K splits */
     const float* w_winograd; /* optional [16][Cout][Cin]: G g G^T of the 3x3 filter (3x3 / stride 1 / pad 1 only) */
     int res_broadcast;  /* 1: res is ONE image [Ho][Wo][ldres] added to every batch element (the per-object halves of the
                            fuser convolutions share the f16 half, model/modules.py:31-41 on cat([x, g])) */
+    const void* w_winograd_f16; /* optional [16][Cout][Cin] IEEE half: the same G g G^T rounded to fp16 (plan_tile 16 only) */
 } xmem_conv_desc;
 
 size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);

@@ -70,3 +70,54 @@ def test_network_480p_vs_oracle(hip_net, ref_net):
     d = (gs[2].cpu() - rs[2]).abs()
     mism = (gs[2].cpu().argmax(1) != rs[2].argmax(1)).float().mean()
     assert float(d.mean()) < 1e-4 and float(d.max()) < 3e-2 and float(mism) < 2e-4, (float(d.mean()), float(d.max()), float(mism))
+
+
+def test_reduced_precision_mode_is_opt_in_and_close(synth_sd):
+    """`precision='fp16'` (Winograd-domain operands in fp16 on the fp16 MFMA, fp32 accumulation; the counterpart
+    of the reference's autocast loop).  Outside the fp32 parity contract: checked against the fp32 path with the tolerance
+    an 11-bit mantissa gives, on a conv, on the network stages and end to end (IoU vs the reference-recorded clip); the
+    permanent-memory preload stays fp32 and the default mode is untouched."""
+    import ast
+    import numpy as np
+    from conftest import load_golden
+    from oracle import cpu_ref as R
+    from xmem2_amd import ops
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.network import XMem
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    g = torch.Generator().manual_seed(3)
+    # one 3x3 convolution, both modes, vs torch fp32
+    x = torch.randn(1, 256, 30, 54, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) * 0.02
+    ref = torch.nn.functional.conv2d(x, w, padding=1)
+    cw = ops.ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), torch.ones(256).cuda(), torch.zeros(256).cuda(), 1, 1)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y32 = ops.conv2d(xin, cw).permute(0, 3, 1, 2).cpu()
+    with ops.precision('fp16'):
+        y16 = ops.conv2d(xin, cw).permute(0, 3, 1, 2).cpu()
+    scale = float(ref.abs().max())
+    e32, e16 = float((y32 - ref).abs().max()) / scale, float((y16 - ref).abs().max()) / scale
+    print(f'3x3 conv 256->256: max err / scale fp32 {e32:.2e}, fp16 mode {e16:.2e}')
+    assert e32 < 1e-5 and 1e-6 < e16 < 4e-3, (e32, e16)            # the fp16 path really ran (and is fp16-class accurate)
+    with pytest.raises(ValueError):
+        XMem({'precision': 'int8'}, None)
+    # end to end on the reference-recorded 480p clip
+    gold = load_golden('e2e_480p_1obj')
+    cfg = ast.literal_eval(str(gold['config']))
+    net = XMem(dict(cfg, precision='fp16'), None).to('cuda').eval()
+    net.load_weights(synth_sd)
+    t = int(gold['shape'][0])
+    frames = torch.from_numpy(synthetic_frames(t, 480, 854)).cuda(); masks = torch.from_numpy(synthetic_masks(t, 1, 480, 854)).cuda()
+    core = InferenceCore(net, cfg)
+    core.set_all_labels([1])
+    core.put_to_permanent_memory(frames[0], masks[0])
+    out, perr = [], 0.0
+    for ti in range(t):
+        mk = masks[ti] if ti == 0 else None
+        p = core.step(frames[ti], mk, [1] if mk is not None else None, end=(ti == t - 1), do_not_add_mask_to_memory=(mk is not None))
+        out.append(ops.argmax_u8(p).cpu().numpy())
+        perr = max(perr, float(np.abs(p[:, 4::8, 4::8].cpu().numpy() - gold['prob_ds8'][ti]).mean()))
+    got, ref_m = np.stack(out), gold['argmax']
+    iou = ((got == 1) & (ref_m == 1)).sum() / max(((got == 1) | (ref_m == 1)).sum(), 1)
+    print(f'fp16 mode, 480p clip: IoU vs the reference masks {iou:.5f}, argmax mismatch {(got != ref_m).mean():.2e}, mean |dp| {perr:.2e}')
+    assert iou >= 0.99 and perr < 5e-3

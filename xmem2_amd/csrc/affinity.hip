@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
 // Source: the query's global list, or - when its 64-query tile overflowed - the per-split lists of the safe kernel.
 // Output: sorted top-k, softmax without max shift (memory_util.py:48-49).
 #define AFM_LIGHT 64
-#define AFM_HEAVY 1408      // >= max(AFW_GCAP, 8 fallback splits x AFF_OUTCAP = 704)
+#define AFM_HEAVY 1408      // >= max(AFW_GCAP, 16 fallback splits x AFF_OUTCAP = 1408)
 __device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb) {
     fb = ovf[q >> 6] != 0;
     if (!fb) { const int t = gcnt[q]; return t > AFW_GCAP ? AFW_GCAP : t; }
@@ -969,8 +969,8 @@ inline int bound_stride(int total_tiles) {
 
 struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
-#define AFF_FB_GRID 32      // persistent workgroups of the safe fallback pass
-inline int fallback_splits(int HW) { (void)HW; return 8; }
+#define AFF_FB_GRID 128     // persistent workgroups of the safe fallback pass (a scene cut flags every tile: ~0.7 ms at B32)
+inline int fallback_splits(int HW) { (void)HW; return 16; }
 WsLayout ws_layout(int HW) {
     WsLayout w;
     w.fsplits = fallback_splits(HW);

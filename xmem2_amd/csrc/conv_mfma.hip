@@ -566,11 +566,172 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(WinoArgs p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// REDUCED-PRECISION MODE (opt-in, plan_tile 16): the Winograd-domain operands V = B^T d B and U = G g G^T are stored in
+// fp16 and contracted on v_mfma_f32_32x32x16_f16 (fp32 accumulation, 16x the fp32 MFMA rate); transforms, epilogue and
+// every other kernel stay fp32.  Mirrors the reference's fp16-autocast GPU loop (inference/run_on_video.py:76); it is
+// outside the fp32 parity contract and is reported under its own bench key.
+// ----------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__global__ void wino_input_f16_kernel(const float* __restrict__ in, int ldin, int B, int H, int W, int C, int th, int tw,
+                                      int relu_in, _Float16* __restrict__ V) {
+    const int C4 = C >> 2;
+    const size_t P = (size_t)B * th * tw;
+    const size_t total = P * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t t = e / C4;
+        const int tx = (int)(t % tw); size_t r = t / tw;
+        const int ty = (int)(r % th);
+        const int b = (int)(r / th);
+        f32x4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = 2 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = 2 * tx - 1 + j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * ldin + c4 * 4);
+                    if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                d[i][j] = v;
+            }
+        }
+        f32x4 u[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u[0][j] = d[0][j] - d[2][j];
+            u[1][j] = d[1][j] + d[2][j];
+            u[2][j] = d[2][j] - d[1][j];
+            u[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v[4] = {u[i][0] - u[i][2], u[i][1] + u[i][2], u[i][2] - u[i][1], u[i][1] - u[i][3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f16x4 hv;
+                hv.x = (_Float16)v[j].x; hv.y = (_Float16)v[j].y; hv.z = (_Float16)v[j].z; hv.w = (_Float16)v[j].w;
+                *reinterpret_cast<f16x4*>(V + ((size_t)(i * 4 + j) * P + t) * C + c4 * 4) = hv;
+            }
+        }
+    }
+}
+
+// M[xi][m][n] = sum_k V[xi][m][k] * U[xi][n][k]  (fp16 x fp16 -> fp32).  One workgroup: BM x BN outputs of one tile position,
+// 4 waves (2 x 2), wave tile (BM/2) x (BN/2) of 32x32 MFMA blocks, BK = 64 halfs per stage: register-staged global loads one
+// stage ahead, single LDS buffer (144-byte rows: an odd multiple of 16 B -> conflict-free ds_read_b128 fragments).
+struct WinoF16Args {
+    const _Float16* V; const _Float16* U; float* M;
+    int P, Cin, Cout, tiles_m, tiles_n;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wino_gemm_f16_kernel(WinoF16Args p) {
+    constexpr int BK = 64, LDB = 144;                 // bytes per LDS row
+    constexpr int TM = BM / 64, TN = BN / 64;         // 32x32 blocks per wave in M / N
+    constexpr int CA = BM * 8 / 256, CB = BN * 8 / 256;   // 16-byte chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    unsigned char* As = smem16;
+    unsigned char* Bs = smem16 + BM * LDB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int xi = blockIdx.y;
+    const unsigned char* gA = reinterpret_cast<const unsigned char*>(p.V + (size_t)xi * p.P * p.Cin);
+    const unsigned char* gB = reinterpret_cast<const unsigned char*>(p.U + (size_t)xi * p.Cout * p.Cin);
+    const size_t rowb = (size_t)p.Cin * 2;            // bytes per operand row
+
+    size_t a_off[CA], b_off[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+        a_off[i] = (size_t)min(m0 + row, p.P - 1) * rowb + ch * 16;       // rows past M are clamped (never stored)
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+        b_off[i] = (size_t)min(n0 + row, p.Cout - 1) * rowb + ch * 16;
+    }
+    f32x4 ra[CA], rb[CB];                             // raw 16-byte chunks
+    auto load_stage = [&](int kt) {
+        const size_t kb = (size_t)kt * BK * 2;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(gA + a_off[i] + kb);
+#pragma unroll
+        for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(gB + b_off[i] + kb);
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) { const int c = tid + 256 * i; *reinterpret_cast<f32x4*>(As + (c >> 3) * LDB + (c & 7) * 16) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) { const int c = tid + 256 * i; *reinterpret_cast<f32x4*>(Bs + (c >> 3) * LDB + (c & 7) * 16) = rb[i]; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.Cin / BK;
+    load_stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                              // previous stage's fragment reads are done
+        store_stage();
+        __syncthreads();
+        if (kt + 1 < nk) load_stage(kt + 1);          // next stage in flight under this stage's MFMAs
+        const unsigned char* a0 = As + (wm * (BM / 2) + l31) * LDB + lh * 16;
+        const unsigned char* b0 = Bs + (wn * (BN / 2) + l31) * LDB + lh * 16;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f16x8*>(a0 + i * 32 * LDB + kk * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f16x8*>(b0 + j * 32 * LDB + kk * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* gM = p.M + (size_t)xi * p.P * p.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                if (m < p.P) gM[(size_t)m * p.Cout + n] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; };
 
 inline bool wino_ok(const xmem_conv_desc* d) {
     return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
@@ -584,7 +745,7 @@ int validate(const xmem_conv_desc* d) {
     if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
     if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
     if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
-    if (d->plan_tile < 0 || d->plan_tile > 15 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
+    if (d->plan_tile < 0 || d->plan_tile > 16 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
     return XMEM_OK;
 }
 
@@ -602,11 +763,19 @@ Plan make_plan(const xmem_conv_desc* d) {
     pl.generic = false;
     pl.wino = false;
     pl.fused = 0;
+    pl.f16 = false;
     if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
     if (d->plan_tile > 0) {
         static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
         int t = d->plan_tile;
+        if (t == 16) {                     // reduced-precision Winograd (opt-in); falls back to the fp32 Winograd tile 64x64
+            if (wino_ok(d) && d->w_winograd_f16 && d->Cin % 64 == 0) {
+                pl.wino = true; pl.f16 = true; pl.bm = 0; pl.bn = 0; pl.nk = d->Cin / 64; pl.splitk = 1; pl.kt_per_split = pl.nk;
+                return pl;
+            }
+            t = 9;
+        }
         if (t > 12) {                      // 13..15: fused Winograd GEMM + output transform {128x64, 64x64, 64x128}, BK 32
             if (wino_ok(d)) { pl.wino = true; pl.fused = t - 12; }
             t = (t == 13) ? 2 : 3;         // fall back to a direct tile when Winograd is not applicable
@@ -679,6 +848,8 @@ extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
     if (validate(d) != XMEM_OK) return 0;
     Plan pl = make_plan(d);
     int Ho, Wo; out_dims(d, Ho, Wo);
+    if (pl.wino && pl.f16) return align_up((size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cin * 2, 256) +
+                                  (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cout * sizeof(float);
     if (pl.wino && pl.fused) return (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cin * sizeof(float);
     if (pl.wino) return (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * (d->Cin + d->Cout) * sizeof(float);
     if (pl.splitk == 1) return 0;
@@ -701,6 +872,39 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
     a.tiles_m = pl.bm ? cdiv(a.M, pl.bm) : 0; a.tiles_n = pl.bn ? cdiv(a.Cout, pl.bn) : 0;
     a.raw = 0; a.res_mod = d->res_broadcast ? Ho * Wo : 0; a.in_gstride = 0; a.w_gstride = 0; a.out_gstride = 0;
+    if (pl.wino && pl.f16) {
+        const int th = cdiv(Ho, 2), tw = cdiv(Wo, 2);
+        const size_t P = (size_t)d->B * th * tw;
+        const size_t vbytes = align_up((size_t)16 * P * d->Cin * 2, 256);
+        const size_t need = vbytes + (size_t)16 * P * d->Cout * sizeof(float);
+        if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
+        if (P > 0x7fffffff) return XMEM_ERR_UNSUPPORTED;
+        _Float16* V = reinterpret_cast<_Float16*>(workspace);
+        float* Mt = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + vbytes);
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        size_t tot = P * (d->Cin / 4);
+        int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wino_input_f16_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
+                           d->relu_in, V);
+        WinoF16Args fa;
+        fa.V = V; fa.U = reinterpret_cast<const _Float16*>(d->w_winograd_f16); fa.M = Mt;
+        fa.P = (int)P; fa.Cin = d->Cin; fa.Cout = d->Cout;
+        // 128x128 tiles once they fill the chip, 64x64 for the small (1/16-resolution, few-channel) layers
+        const long big = (long)cdiv((int)P, 128) * cdiv(d->Cout, 128) * 16;
+        if (big >= 512 && d->Cout >= 128) {
+            fa.tiles_m = cdiv((int)P, 128); fa.tiles_n = cdiv(d->Cout, 128);
+            hipLaunchKernelGGL((wino_gemm_f16_kernel<128, 128>), dim3(fa.tiles_m * fa.tiles_n, 16), dim3(256), (size_t)256 * 144, s, fa);
+        } else {
+            fa.tiles_m = cdiv((int)P, 64); fa.tiles_n = cdiv(d->Cout, 64);
+            hipLaunchKernelGGL((wino_gemm_f16_kernel<64, 64>), dim3(fa.tiles_m * fa.tiles_n, 16), dim3(256), (size_t)128 * 144, s, fa);
+        }
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        tot = P * (d->Cout / 4);
+        blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wino_output_kernel, dim3(blocks), dim3(256), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
+                           d->res, d->ldres, d->res_broadcast ? 1 : 0, d->relu_out, d->out, d->ldout);
+        return xmem_check_launch();
+    }
     if (pl.wino) {
         const int th = cdiv(Ho, 2), tw = cdiv(Wo, 2);
         const size_t P = (size_t)d->B * th * tw;

@@ -276,8 +276,17 @@ class InferenceCore:
 
     @_on_network_device
     def put_to_permanent_memory(self, image, mask, ti=None):
-        """inference_core.py:154-179."""
+        """inference_core.py:154-179.  Always full fp32, also when the network runs the frame loop in its reduced-precision mode
+        (the reference preloads outside its autocast region, inference/run_on_video.py:59-66 vs :76)."""
         self._drop_prefetch()
+        net, mem = self.network, self.memory
+        prev, net._call_precision = getattr(net, '_call_precision', None), 'fp32'
+        try:
+            return self._put_to_permanent_memory(image, mask, ti)
+        finally:
+            net._call_precision = prev
+
+    def _put_to_permanent_memory(self, image, mask, ti):
         image4, hw, hw_p = self._pack(image)
         net, mem = self.network, self.memory
         key, shrinkage, selection, f16, _, _ = net.encode_key_nhwc(image4, need_sk=True, need_ek=True)

@@ -35,8 +35,14 @@ class XMem:
         self._cbam = {}
         # launch-bound stages (61 convolutions + ~40 small kernels per frame) are replayed as HIP graphs
         self.use_graphs = os.environ.get('XMEM_HIP_GRAPHS', '1') != '0'
+        # 'fp32' (default: the parity contract) | 'fp16' (opt-in: Winograd-domain operands in fp16, fp32 accumulation -
+        # the counterpart of the reference's autocast loop; the permanent-memory preload stays fp32 as in run_on_video.py:66)
+        self.precision = config.get('precision', os.environ.get('XMEM_PRECISION', 'fp32'))
+        if self.precision not in ('fp32', 'fp16'):
+            raise ValueError(f"config['precision'] must be 'fp32' or 'fp16', got {self.precision!r}")
         self._stages = {}
         self._zeros = {}
+        self._call_precision = None      # per-call override (InferenceCore preloads permanent memory in fp32)
         # the decoder's skip convolutions depend only on f8 / f4: inside the captured key-encoder graph they run on a
         # forked stream next to the small-grid layer2 / layer3 kernels.  Measured neutral on MI355X (A/B on one box:
         # 272 vs 273 fps), so it is off by default (XMEM_OVERLAP=1 enables it).
@@ -230,20 +236,23 @@ class XMem:
         """Run `fn(*inputs)` eagerly, or capture it once per (name, shapes, flags) into a HIP graph with static
         input / output buffers and replay it.  Kernels are launched through ctypes on torch's current stream, which
         is the capturing stream inside torch.cuda.graph, so they are captured like any other launch."""
+        prec = self._call_precision or self.precision
         if not self.use_graphs or ops.eager_only():
-            return fn(*inputs)
-        full_key = (name, key) + tuple(tuple(t.shape) if t is not None else None for t in inputs)
+            with ops.precision(prec):
+                return fn(*inputs)
+        full_key = (name, key, prec) + tuple(tuple(t.shape) if t is not None else None for t in inputs)
         st = self._stages.get(full_key)
         if st is None:
             # inputs listed in `alias` are themselves stable buffers (outputs of another stage): use them in place
             static_in = [(t if i in alias else t.clone()) if t is not None else None for i, t in enumerate(inputs)]
             # warm-up: sizes every workspace before the capture.  Inputs the stage updates in place (`mutates`: the hidden
             # state) are cloned for it, otherwise warm-up + first replay would advance the state twice.
-            fn(*[(t.clone() if (i in mutates and t is not None) else t) for i, t in enumerate(static_in)])
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = fn(*static_in)
+            with ops.precision(prec):
+                fn(*[(t.clone() if (i in mutates and t is not None) else t) for i, t in enumerate(static_in)])
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = fn(*static_in)
             st = (graph, static_in, static_out)
             self._stages[full_key] = st
         graph, static_in, static_out = st
@@ -422,7 +431,8 @@ class XMem:
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
         if self.use_graphs and not ops.eager_only():
             for k, st in self._stages.items():
-                if k[0] != 'segment' or k[1][-2] != slot or k[1][-1] != owner or tuple(st[1][3].shape) != shape:
+                if k[0] != 'segment' or k[2] != (self._call_precision or self.precision) or k[1][-2] != slot or k[1][-1] != owner \
+                        or tuple(st[1][3].shape) != shape:
                     continue
                 if (h_out is not None and k[1][2] != bool(h_out)) or (has_skips is not None and k[1][3] != bool(has_skips)):
                     continue

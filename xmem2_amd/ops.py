@@ -91,9 +91,30 @@ def _req(t, name):
     return t
 
 
+# Arithmetic mode of the 3x3 / stride-1 convolutions.  'fp32' (default, the parity contract) or 'fp16': OPT-IN reduced
+# precision - the Winograd-domain operands are rounded to fp16 and multiplied on the fp16 MFMA with fp32 accumulation (the
+# counterpart of the reference's autocast loop, inference/run_on_video.py:76).  Set per call tree by XMem (`precision`).
+_PRECISION = 'fp32'
+
+
+class precision:
+    def __init__(self, mode):
+        if mode not in ('fp32', 'fp16'):
+            raise ValueError(f'unknown precision {mode!r} (fp32 | fp16)')
+        self.mode = mode
+
+    def __enter__(self):
+        global _PRECISION
+        self.prev, _PRECISION = _PRECISION, self.mode
+
+    def __exit__(self, *exc):
+        global _PRECISION
+        _PRECISION = self.prev
+
+
 class ConvWeights:
     """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
-    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu')
+    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu', 'wu_f16')
 
     def __init__(self, w, scale, shift, stride, pad, cin_true=None, winograd=True):
         self.w, self.scale, self.shift = w, scale, shift
@@ -101,9 +122,12 @@ class ConvWeights:
         self.stride, self.pad = stride, pad
         self.cin_true = cin_true if cin_true is not None else self.cin     # un-padded Cin (algorithmic FLOPs)
         self.wu = None
+        self.wu_f16 = None
         if winograd and self.kh == 3 and self.kw == 3 and stride == 1 and pad == 1 and self.cin % 32 == 0 \
                 and self.cout % 4 == 0 and self.cout >= 32:
             self.wu = winograd_weights(w)
+            if self.cin % 64 == 0:
+                self.wu_f16 = self.wu.to(torch.float16).contiguous()      # reduced-precision mode only
 
 
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
@@ -216,6 +240,10 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.out = out.data_ptr(); d.ldout = out_ld
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
     d.w_winograd = cw.wu.data_ptr() if cw.wu is not None else None
+    d.w_winograd_f16 = None
+    if _PRECISION == 'fp16' and cw.wu_f16 is not None and plan is None and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0):
+        d.w_winograd_f16 = cw.wu_f16.data_ptr()
+        plan = (16, 1)                       # the library falls back to the fp32 Winograd tile if its own conditions fail
     key = f'{B}x{H}x{W}x{cin}/{ldin}->{cw.cout}/{out_ld} k{cw.kh}s{cw.stride}p{cw.pad} r{int(res is not None)}{int(relu_in)}{int(relu_out)}'
     if plan is None:
         plan = _load_plans().get(key) or _tuned_now.get(key)
