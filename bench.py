@@ -244,6 +244,8 @@ FAMILIES = (('conv', ('conv_', 'wino_')),
 
 def family_of(name):
     n = name[5:] if name.startswith('void ') else name
+    if n.startswith('_Z'):                               # a name the tracer could not demangle (_Float16 arguments)
+        n = n[2:].lstrip('0123456789')
     for fam, prefixes in FAMILIES:
         if n.startswith(prefixes):
             return fam
@@ -307,7 +309,7 @@ def run_traced_child(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def committed_pmc(workload):
+def committed_pmc(workload, precision='fp32'):
     """HBM-side bytes per frame from the committed PMC passes (profiles/r*_pmc_per_frame*.json), quoted ONLY when they
     were recorded for exactly this build of the kernels (source digest match) - otherwise None, never a stale number."""
     from xmem2_amd.build import source_digest
@@ -319,7 +321,7 @@ def committed_pmc(workload):
                 j = json.load(f)
         except Exception:
             continue
-        if j.get('source_digest') == dig and j.get('workload', 'b32') == workload:
+        if j.get('source_digest') == dig and j.get('workload', 'b32') == workload and j.get('precision', 'fp32') == precision:
             best = (path, j)
     if best is None:
         return None
@@ -544,7 +546,7 @@ def main():
                 if aff_us:
                     line['roofline']['timed_region_trace_us_per_frame'] = aff_us
                     line['roofline']['frac_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
-        pmc = committed_pmc(args.workload)
+        pmc = committed_pmc(args.workload, args.precision)
         if pmc is not None:
             line['roofline']['traffic'] = pmc['families'].get('affinity')
             line['roofline']['traffic_source'] = pmc['file'] + ' (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this build; bytes per frame)'

@@ -239,8 +239,8 @@ def test_prefetch_keys_is_only_a_hint(hip_net):
         c.prefetch_keys([fr[0], fr[1][:, :64]])
 
 
-@pytest.mark.parametrize('hw,n_obj,perm,steps', [((720, 1280), 1, 3, 3), ((1080, 1920), 2, 1, 2)],
-                         ids=['720p_1obj', '1080p_2obj'])
+@pytest.mark.parametrize('hw,n_obj,perm,steps', [((720, 1280), 1, 3, 3), ((1080, 1920), 2, 1, 2), ((1080, 1920), 5, 1, 1)],
+                         ids=['720p_1obj', '1080p_2obj', '1080p_5obj_config5'])
 def test_e2e_large_frames_vs_oracle(hip_net, ref_net, hw, n_obj, perm, steps):
     """BASELINE configs 4 / 5 frame geometry (720p, 1080p -> padded 1088 x 1920) end to end against the oracle on a few
     frames: permanent preload, batched key hints, one memory frame, 1-2 objects.  Same acceptance as the 480p clips."""
@@ -309,3 +309,39 @@ def test_run_on_video_with_augmented_permanent_memory(tmp_path, hip_net):
     assert core.memory.permanent_work_mem.size == 12 * (hw[0] // 16) * (hw[1] // 16)
     p = core.step(T(frames[1]).cuda(), None, None)
     assert bool(torch.isfinite(p).all()) and float((p.sum(0) - 1).abs().max()) < 1e-4
+
+
+def test_e2e_480p_three_objects_consolidation_vs_oracle(hip_net, ref_net):
+    """BASELINE config 3 at its stated size: 480p, 3 objects, a long-term consolidation inside the clip (mem_every=2,
+    T_max=4 -> compress_features fires at the 5th temporary frame), batched key hints - against the oracle frame by frame."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    t, hw, K = 13, (480, 854), 3
+    cfg = base_config(mem_every=2, max_mid_term_frames=4, min_mid_term_frames=2, num_prototypes=64)
+    frames = T(synthetic_frames(t, *hw)); masks = T(synthetic_masks(t, K, *hw))
+    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
+    for c in (core, ref):
+        c.set_all_labels([1, 2, 3])
+    core.put_to_permanent_memory(frames[0].cuda(), masks[0].cuda())
+    ref.put_to_permanent_memory(frames[0], masks[0])
+    dev = [frames[i].cuda() for i in range(t)]
+    inter, uni, mism = np.zeros(K), np.zeros(K), 0
+    for i in range(1, t):
+        if (i - 1) % 4 == 0:
+            core.prefetch_keys(dev[i:i + 4])
+        p = core.step(dev[i], None, None, end=(i == t - 1))
+        q = ref.step(frames[i], None, None, end=(i == t - 1))
+        a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
+        mism += int((a != b).sum())
+        for k in range(K):
+            inter[k] += ((a == k + 1) & (b == k + 1)).sum(); uni[k] += ((a == k + 1) | (b == k + 1)).sum()
+        assert float((p.cpu() - q).abs().mean()) < 5e-4, f'frame {i}'
+        m, rm = core.memory, ref.memory
+        assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == \
+               (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size), f'frame {i}'
+    assert core.memory.long_mem.size > 0, 'the clip must include a consolidation'
+    iou = inter / np.maximum(uni, 1)
+    print(f'480p x 3 objects: IoU per object {iou}, argmax mismatch {mism}/{(t - 1) * hw[0] * hw[1]}')
+    assert iou.min() >= 0.999 and mism / ((t - 1) * hw[0] * hw[1]) < 1e-4

@@ -684,6 +684,7 @@ struct HintArgs {
     float* tau0; int* gcnt; int* ovf;
 };
 #define HINT_MAXC 320       // 5 queries x 64 indices
+#define HINT_NB 12          // entries taken from each grid neighbour's list
 
 __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
     constexpr int CK = 64;
@@ -715,14 +716,17 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         if (q >= p.grid_w) nq[nn++] = q - p.grid_w;
         if (q + p.grid_w < p.HW) nq[nn++] = q + p.grid_w;
     }
-    const int T = nn * p.hint_k;
+    // the query's own list in full, the best HINT_NB entries of each neighbour's (the lists are sorted by similarity)
+    const int nbk = p.hint_k < HINT_NB ? p.hint_k : HINT_NB;
+    const int T = p.hint_k + (nn - 1) * nbk;
     const int T4 = (T + 3) & ~3;
     __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < T4; e += 64) {
         float v = -INFINITY;
         if (e < T) {
-            const int li = e / p.hint_k;
-            int o = p.hint_idx[(size_t)nq[li] * p.hint_k + (e - li * p.hint_k)];
+            const int li = e < p.hint_k ? 0 : 1 + (e - p.hint_k) / nbk;
+            const int pos = e < p.hint_k ? e : (e - p.hint_k) - (li - 1) * nbk;
+            int o = p.hint_idx[(size_t)nq[li] * p.hint_k + pos];
             // re-base from the old segment layout to today's
             int sgi = 0, ob = 0;
 #pragma unroll
@@ -744,20 +748,24 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
             }
             if (uniq) {
                 const float* row = p.seg[sgi].key + (size_t)o * CK;
-                float acc = 0.f, aacc = 0.f;
-#pragma unroll 4
-                for (int c4 = 0; c4 < CK; c4 += 4) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(row + c4);
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(op + c4);
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(op + CK + c4);
+                f32x4 xr[CK / 4];                                // the whole row in flight at once
+#pragma unroll
+                for (int c4 = 0; c4 < CK / 4; ++c4) xr[c4] = *reinterpret_cast<const f32x4*>(row + c4 * 4);
+                float accv[4] = {0.f, 0.f, 0.f, 0.f}, aaccv[4] = {0.f, 0.f, 0.f, 0.f};     // four independent chains
+#pragma unroll
+                for (int c4 = 0; c4 < CK / 4; ++c4) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(op + c4 * 4);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(op + CK + c4 * 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float xv = x[j], xx = xv * xv;
+                        const float xv = xr[c4][j], xx = xv * xv;
                         const float t1 = xx * lo[j], t2 = xv * hi[j];
-                        acc += t1; acc += t2;
-                        aacc += fabsf(t1) + fabsf(t2);
+                        accv[j] += t1; accv[j] += t2;
+                        aaccv[j] += fabsf(t1) + fabsf(t2);
                     }
                 }
+                const float acc = (accv[0] + accv[1]) + (accv[2] + accv[3]);
+                const float aacc = (aaccv[0] + aaccv[1]) + (aaccv[2] + aaccv[3]);
                 const float ms = p.seg[sgi].shr ? p.seg[sgi].shr[o] : 1.f;
                 const float est = (acc - bs) * (ms * 0.125f);
                 const float margin = (aacc + fabsf(bs)) * (fabsf(ms) * 0.125f) * 3.2e-5f + 1e-30f;   // > 2 * 130 * 2^-24 * sum|terms|
@@ -1184,17 +1192,35 @@ struct ReadoutArgs {
 };
 
 __global__ void readout_sparse_kernel(ReadoutArgs p) {
+    // one workgroup per (query, object): the k row pointers are resolved once, then the rows stream in batches of six
+    // independent 16-byte loads per thread (the gather is latency-bound: k * C_v * 4 B = 60 KB per query and object)
+    __shared__ const float* rows[AFF_MAX_TOPK];
+    __shared__ float wsm[AFF_MAX_TOPK];
     const int q = blockIdx.x, obj = blockIdx.y;
-    const float* wq = p.w + (size_t)q * p.top_k;
-    const int* iq = p.idx + (size_t)q * p.top_k;
+    if ((int)threadIdx.x < p.top_k) {
+        int i = p.idx[(size_t)q * p.top_k + threadIdx.x];
+        int sg = 0;
+        while (sg < p.n_seg - 1 && i >= p.n[sg]) { i -= p.n[sg]; ++sg; }
+        rows[threadIdx.x] = p.val[obj * p.n_seg + sg] + (size_t)i * p.Cv;
+        wsm[threadIdx.x] = p.w[(size_t)q * p.top_k + threadIdx.x];
+    }
+    __syncthreads();
     for (int c4 = threadIdx.x; c4 * 4 < p.Cv; c4 += blockDim.x) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < p.top_k; ++s) {
-            int i = iq[s];
-            const float ws = wq[s];
-            int sg = 0;
-            while (sg < p.n_seg - 1 && i >= p.n[sg]) { i -= p.n[sg]; ++sg; }
-            const f32x4 v = *reinterpret_cast<const f32x4*>(p.val[obj * p.n_seg + sg] + (size_t)i * p.Cv + c4 * 4);
+        int s = 0;
+        for (; s + 6 <= p.top_k; s += 6) {
+            f32x4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v[u] = *reinterpret_cast<const f32x4*>(rows[s + u] + c4 * 4);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const float ws = wsm[s + u];
+                acc.x += ws * v[u].x; acc.y += ws * v[u].y; acc.z += ws * v[u].z; acc.w += ws * v[u].w;
+            }
+        }
+        for (; s < p.top_k; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rows[s] + c4 * 4);
+            const float ws = wsm[s];
             acc.x += ws * v.x; acc.y += ws * v.y; acc.z += ws * v.z; acc.w += ws * v.w;
         }
         *reinterpret_cast<f32x4*>(p.out + (size_t)obj * p.obj_stride + (size_t)q * p.ldout + c4 * 4) = acc;
