@@ -489,7 +489,7 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
 #define AFW_BQ 128
 #define AFW_WAVES 8
 #define AFW_CAP 80          // per (workgroup, query) LDS candidates
-#define AFW_GCAP 1024       // per-query global candidate list (all splits)
+#define AFW_GCAP 2048       // per-query global candidate list: <= 32 splits x max(top_k, 32) entries each
 
 struct WideArgs {
     SegDev seg[XMEM_MAX_SEGMENTS];
@@ -507,15 +507,17 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Bq = smem;                                 // [128][132]
     float* bsq = Bq + AFW_BQ * AFF_LDB;               // [128]
-    float* tau = bsq + AFW_BQ;                        // [128]
-    int* cnt = reinterpret_cast<int*>(tau + AFW_BQ);  // [128]
-    u64* cand = reinterpret_cast<u64*>(cnt + AFW_BQ); // [128][AFW_CAP]
+    float* tau = bsq + AFW_BQ;                        // [128]   current lower bound of the k-th similarity (only ever raised)
+    int* cnt = reinterpret_cast<int*>(tau + AFW_BQ);  // [128] + flag + pad
+    volatile int* flag = cnt + AFW_BQ;                // "a candidate list is full": every wave joins a tightening episode
+    u64* cand = reinterpret_cast<u64*>(cnt + AFW_BQ + 4); // [128][AFW_CAP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.x * AFW_BQ;
     const int split = blockIdx.y;
+    const int keep = p.top_k > 32 ? p.top_k : 32;     // entries a list is cut back to (>= top_k)
 
     {   // stage the query operand (same arithmetic as affinity_kernel: bit-identical similarities)
         const int q = tid >> 2, part = tid & 3, qg = q0 + q;
@@ -540,11 +542,13 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
         bs += __shfl_xor(bs, 2, 64);
         if (part == 0) {
             bsq[q] = p.qe ? bs : 0.f;
-            float t0 = (qg < p.HW) ? p.tau_init[qg] : INFINITY;
-            if (t0 == -INFINITY) { p.ovf[qg >> 6] = 1; t0 = INFINITY; }      // no usable bound: the safe kernel owns this tile
-            tau[q] = (t0 == INFINITY) ? INFINITY : nextafterf(t0, -INFINITY);
+            // tau0 is reached by >= k elements; elements equal to it must still pass the strict test below.
+            // -inf (no bound at all) is fine: the lists tighten themselves; queries past HW never collect anything.
+            const float t0 = (qg < p.HW) ? (p.tau_init ? p.tau_init[qg] : -INFINITY) : INFINITY;
+            tau[q] = (t0 == INFINITY || t0 == -INFINITY) ? t0 : nextafterf(t0, -INFINITY);
             cnt[q] = 0;
         }
+        if (tid == 0) *flag = 0;
     }
     __syncthreads();
 
@@ -578,26 +582,69 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
         msn = shr ? shr[r] : 1.f;
     };
 
+    // ---- self-tightening candidate lists -------------------------------------------------------------------------------
+    // A lane appends the values of one 32x32 block all-or-nothing (one reservation).  If a list has no room the lane marks the
+    // block for a redo and raises `flag`; every wave joins the episode at its next tile boundary (or from the drain loop at
+    // the end): barrier, each list longer than `keep` is cut back to its best `keep` entries and its bound raised to the k-th
+    // of them (>= k elements reach it, so it is a valid lower bound of the true k-th), barrier.  The wave then contracts the
+    // same tile again and stores only the marked blocks - no vector state lives across an episode.  A list can therefore
+    // never lose a candidate, whatever the initial bound was (-inf included): no overflow path, no second kernel.
+    auto compact = [&](int q, int c) {                // whole wave, wave-uniform q; all c <= AFW_CAP entries are written
+        u64* L = cand + (size_t)q * AFW_CAP;
+        const u64 k0 = lane < c ? L[lane] : 0ull;
+        const u64 k1 = lane + 64 < c ? L[lane + 64] : 0ull;
+        int r0 = 0, r1 = 0;
+        for (int f = 0; f < c; ++f) { const u64 kf = L[f]; r0 += (int)(kf > k0); r1 += (int)(kf > k1); }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < c && r0 < keep) L[r0] = k0;        // keys are unique: the ranks are a permutation
+        if (lane + 64 < c && r1 < keep) L[r1] = k1;
+        if (lane < c && r0 == p.top_k - 1) tau[q] = fmaxf(tau[q], nextafterf(key_val(k0), -INFINITY));
+        if (lane + 64 < c && r1 == p.top_k - 1) tau[q] = fmaxf(tau[q], nextafterf(key_val(k1), -INFINITY));
+        if (lane == 0) cnt[q] = c < keep ? c : keep;
+    };
+    auto episode = [&]() -> bool {                    // every wave of the workgroup calls this the same number of times
+        __syncthreads();
+        const bool f = *flag != 0;
+        if (f) {
+            for (int q = wave; q < AFW_BQ; q += AFW_WAVES) {
+                int c = cnt[q];
+                c = c > AFW_CAP ? AFW_CAP : c;
+                if (c > keep) compact(q, c);
+            }
+            if (tid == 0) *flag = 0;
+            __syncthreads();
+        }
+        return f;
+    };
+
     float my_tau[4], my_bs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { my_tau[i] = tau[i * 32 + l31]; my_bs[i] = bsq[i * 32 + l31]; }
+    for (int i = 0; i < 4; ++i) my_bs[i] = bsq[i * 32 + l31];
     constexpr float inv_sqrt = 0.125f;               // sqrt(C_k) = 8: (x * ms) / 8 == x * (ms / 8) bit for bit
 
-    issue_loads(t_begin + wave);
-    for (int tb = t_begin; tb < t_end; tb += AFW_WAVES) {
+    int cur = t_begin + wave;                         // this wave's current tile (units of its split's tile list)
+    unsigned redo = 0;                                // per lane: blocks of tile `cur` that found their list full
+    issue_loads(cur);
+    for (;;) {
+        if (*flag) episode();                         // wave-uniform LDS read
+        if (!n_active) break;                         // past the end of this wave's tiles
+#pragma unroll
+        for (int i = 0; i < 4; ++i) my_tau[i] = tau[i * 32 + l31];
         f32x4 a[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) a[t] = an[t];
         const float ms_mine = msn;
-        const bool have = n_active;
         const int row0 = n_row0, segn = n_segn, base = n_base;
-        issue_loads(tb + AFW_WAVES + wave);           // next tile's rows in flight under this tile's MFMAs
-        if (!have) continue;
+        const bool is_redo = __any(redo != 0);
+        issue_loads(cur + AFW_WAVES);                 // next tile's rows in flight under this tile's MFMAs
         f32x16 c[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            float nb = -my_bs[i];
+            asm volatile("" : "+v"(nb));              // re-materialise per tile (64 loop-invariant registers otherwise)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[i][r] = -my_bs[i];
+            for (int r = 0; r < 16; ++r) c[i][r] = nb;
+        }
         const float* bq = Bq + l31 * AFF_LDB + lh * 4;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -621,6 +668,7 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) msr[r] = __shfl(ms_mine, (r & 3) + 8 * (r >> 2) + 4 * lh, 64) * inv_sqrt;
         const bool full = row0 + AFF_ROWS <= segn;        // wave-uniform
+        unsigned todo = 0;                                // blocks of this lane to store: those that pass the bound
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float best = -INFINITY;
@@ -634,37 +682,53 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
                     best = fmaxf(best, rr < segn ? c[i][r] * msr[r] : -INFINITY);
                 }
             }
-            if (best > my_tau[i]) {                    // rare: walk the 16 values of this lane
+            if (best > my_tau[i]) todo |= 1u << i;
+        }
+        if (is_redo) todo &= redo;                        // a repeated tile stores only what failed before
+        redo = 0;
+        if (__any(todo != 0)) {                           // rare: some lane of the wave has candidates
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!(todo & (1u << i))) continue;
                 const int q = i * 32 + l31;
+                const float tq = my_tau[i];
+                int n = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float x = c[i][r] * msr[r];
-                    if (rr < segn && x > my_tau[i]) {
-                        const int slot = atomicAdd(&cnt[q], 1);
-                        if (slot < AFW_CAP) cand[(size_t)q * AFW_CAP + slot] = pack_key(x, base + rr);
-                        else {                                     // LDS list full: straight to the query's global list
-                            const int gs = atomicAdd(&p.gcnt[q0 + q], 1);
-                            if (gs < AFW_GCAP) p.gcand[(size_t)(q0 + q) * AFW_GCAP + gs] = pack_key(x, base + rr);
-                            else p.ovf[(q0 + q) >> 6] = 1;
-                        }
+                    n += (int)(rr < segn && c[i][r] * msr[r] > tq);
+                }
+                if (n == 0) continue;
+                const int slot = atomicAdd(&cnt[q], n);
+                if (slot + n <= AFW_CAP) {
+                    int w2 = slot;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float x = c[i][r] * msr[r];
+                        if (rr < segn && x > tq) cand[(size_t)q * AFW_CAP + w2++] = pack_key(x, base + rr);
                     }
+                } else {
+                    atomicSub(&cnt[q], n);                // no room: the list is cut back in the episode, the tile repeated
+                    *flag = 1;
+                    redo |= 1u << i;
                 }
             }
         }
+        if (__any(redo != 0)) issue_loads(cur);           // same tile again (after the episode at the loop top)
+        else cur += AFW_WAVES;
     }
-    __syncthreads();
-    // ---- flush: reserve room in the query's global list, copy; any truncation flags the 64-query tile ----
+    while (episode()) {}                                  // drain: other waves may still need partners for an episode
+    // ---- flush: every list cut back to <= keep entries, then copied behind the query's global list ----
     for (int q = wave; q < AFW_BQ; q += AFW_WAVES) {
         const int qg = q0 + q;
         if (qg >= p.HW) continue;
         int c = cnt[q];
         if (c == 0) continue;
-        c = c > AFW_CAP ? AFW_CAP : c;                    // the excess went to the global list directly
+        if (c > keep) { compact(q, c); __builtin_amdgcn_wave_barrier(); c = keep; }
         int gb = 0;
         if (lane == 0) gb = atomicAdd(&p.gcnt[qg], c);
         gb = __shfl(gb, 0, 64);
-        if (gb + c > AFW_GCAP && lane == 0) p.ovf[qg >> 6] = 1;
         for (int s2 = lane; s2 < c && gb + s2 < AFW_GCAP; s2 += 64) p.gcand[(size_t)qg * AFW_GCAP + gb + s2] = cand[(size_t)q * AFW_CAP + s2];
     }
 }
@@ -797,7 +861,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
 // Source: the query's global list, or - when its 64-query tile overflowed - the per-split lists of the safe kernel.
 // Output: sorted top-k, softmax without max shift (memory_util.py:48-49).
 #define AFM_LIGHT 64
-#define AFM_HEAVY 1408      // >= max(AFW_GCAP, 16 fallback splits x AFF_OUTCAP = 1408)
+#define AFM_HEAVY 2048      // >= AFW_GCAP
 __device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb) {
     fb = ovf[q >> 6] != 0;
     if (!fb) { const int t = gcnt[q]; return t > AFW_GCAP ? AFW_GCAP : t; }
@@ -1064,7 +1128,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     // one 8-wave workgroup per CU: splits so that query tiles x splits fills (at most) the 256 CUs, >= 8 tiles per wave
     int sp = 256 / qt128; if (sp < 1) sp = 1;
     { int maxs = tiles / (8 * AFW_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
-    if (sp > 64) sp = 64;
+    if (sp > 32) sp = 32;                              // AFW_GCAP = 32 splits x 64 entries
     w.sub_tiles = tiles;
     w.tiles_per_split = cdiv(tiles, sp);
     w.splits = cdiv(tiles, w.tiles_per_split);
@@ -1108,29 +1172,15 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }
     {
-        const size_t lds = ((size_t)AFW_BQ * AFF_LDB + 3 * AFW_BQ) * sizeof(float) + (size_t)AFW_BQ * AFW_CAP * sizeof(u64);
+        const size_t lds = ((size_t)AFW_BQ * AFF_LDB + 3 * AFW_BQ + 4) * sizeof(float) + (size_t)AFW_BQ * AFW_CAP * sizeof(u64);
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
         hipLaunchKernelGGL(affinity_wide_kernel, dim3(qt128, w.splits), dim3(512), lds, s, w);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }
-    {
-        // safe kernel on the (normally zero) overflowed 64-query tiles: small grid, worst-case candidate buffers in global scratch
-        const int qtiles = cdiv(HW, AFF_BQ);
-        AffPlan pl = aff_plan(tiles, HW, top_k, false);
-        a.tau_init = tau0; a.ovf = ovf;
-        a.limit = pl.limit; a.cap = pl.cap; a.tile_stride = 1; a.chunk = 0; a.sub_tiles = tiles;
-        a.tiles_per_split = cdiv(tiles, wl.fsplits);
-        a.splits = cdiv(tiles, a.tiles_per_split);
-        a.merge_splits = a.splits;
-        a.cand_spill = reinterpret_cast<u64*>(ws + wl.spill_off);
-        const size_t lds3 = ((size_t)AFF_BQ * AFF_LDB + 3 * AFF_BQ + 4) * sizeof(float);
-        if (qtiles > AFF_FB_MAXTILES) return XMEM_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((affinity_kernel<64, 3>), dim3(AFF_FB_GRID), dim3(256), lds3, s, a);
-        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-        hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), 0, s, gcand, gcnt, ovf, a.part_key, a.part_cnt,
-                           a.splits, HW, top_k, out_w, out_idx, out_sim);
-    }
+    // no overflow path: the lists of the wide kernel tighten themselves (see its episodes); the merge reads the global lists
+    hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), 0, s, gcand, gcnt, ovf, a.part_key, a.part_cnt,
+                       0, HW, top_k, out_w, out_idx, out_sim);
     return xmem_check_launch();
 }
 
