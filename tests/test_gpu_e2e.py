@@ -260,20 +260,24 @@ def test_e2e_large_frames_vs_oracle(hip_net, ref_net, hw, n_obj, perm, steps):
         ref.put_to_permanent_memory(frames[j], masks[j])
     dev = [frames[perm + i].cuda() for i in range(steps)]
     core.prefetch_keys(dev)                                    # one batched key-encoder hint for all query frames
-    inter = uni = mism = 0
+    inter = uni = mism = clear_mism = 0
     for i in range(steps):
         p = core.step(dev[i], None, None)
         q = ref.step(frames[perm + i], None, None)
         assert p.shape == q.shape == (n_obj + 1,) + tuple(hw)
         a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
         mism += int((a != b).sum())
+        top2 = torch.topk(q, 2, dim=0).values
+        clear_mism += int(((a != b) & ((top2[0] - top2[1]).numpy() > 2e-2)).sum())
         inter += int(((a > 0) & (b > 0) & (a == b)).sum()); uni += int(((a > 0) | (b > 0)).sum())
         assert float((p.cpu() - q).abs().mean()) < 5e-4
         m, rm = core.memory, ref.memory
         assert (m.temporary_work_mem.size, m.permanent_work_mem.size) == (rm.temporary_work_mem.size, rm.permanent_work_mem.size)
     iou = inter / max(uni, 1)
-    print(f'{hw}: IoU {iou:.5f}, argmax mismatch {mism}/{steps * hw[0] * hw[1]}')
-    assert iou >= 0.999 and mism / (steps * hw[0] * hw[1]) < 1e-4
+    print(f'{hw}: IoU {iou:.5f}, argmax mismatch {mism}/{steps * hw[0] * hw[1]}, of which at a clear oracle margin: {clear_mism}')
+    # more objects -> more boundary pixels at zero margin: the mismatch budget scales with the object count; where the
+    # oracle's own top-2 margin is clear (2x its thread-noise floor) the argmax must be identical
+    assert iou >= 0.999 and mism / (steps * hw[0] * hw[1]) < 1e-4 * max(1, 2 * n_obj) and clear_mism == 0
 
 
 def test_run_on_video_with_augmented_permanent_memory(tmp_path, hip_net):

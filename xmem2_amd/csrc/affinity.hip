@@ -699,8 +699,16 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
                     n += (int)(rr < segn && c[i][r] * msr[r] > tq);
                 }
                 if (n == 0) continue;
-                const int slot = atomicAdd(&cnt[q], n);
-                if (slot + n <= AFW_CAP) {
+                // reserve n slots or nothing (a failed add-then-give-back would corrupt the count if another lane's reservation
+                // succeeded in between): compare-and-swap on the list length
+                int slot = *reinterpret_cast<volatile int*>(&cnt[q]);
+                for (;;) {
+                    if (slot + n > AFW_CAP) { slot = -1; break; }
+                    const int seen = atomicCAS(&cnt[q], slot, slot + n);
+                    if (seen == slot) break;
+                    slot = seen;
+                }
+                if (slot >= 0) {
                     int w2 = slot;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -708,8 +716,7 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
                         const float x = c[i][r] * msr[r];
                         if (rr < segn && x > tq) cand[(size_t)q * AFW_CAP + w2++] = pack_key(x, base + rr);
                     }
-                } else {
-                    atomicSub(&cnt[q], n);                // no room: the list is cut back in the episode, the tile repeated
+                } else {                                   // no room: the list is cut back in the episode, the tile repeated
                     *flag = 1;
                     redo |= 1u << i;
                 }
@@ -882,6 +889,7 @@ __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __rest
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int q = blockIdx.x * 16 + g;
     float* sv = s_v[g]; int* si = s_i[g];
+    for (int r = l; r < top_k; r += 16) { sv[r] = -INFINITY; si[r] = 0; }     // never an out-of-range index, whatever happens upstream
     bool fb = false;
     const int total = q < HW ? merge_count(gcnt, ovf, part_cnt, fsplits, HW, q, fb) : 0;
     const bool light = q < HW && total <= AFM_LIGHT;
