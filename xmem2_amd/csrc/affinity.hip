@@ -869,20 +869,21 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
 // Output: sorted top-k, softmax without max shift (memory_util.py:48-49).
 #define AFM_LIGHT 64
 #define AFM_HEAVY 2048      // >= AFW_GCAP
-__device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb) {
-    fb = ovf[q >> 6] != 0;
-    if (!fb) { const int t = gcnt[q]; return t > AFW_GCAP ? AFW_GCAP : t; }
+__device__ __forceinline__ int merge_count(const int* gcnt, const int* ovf, const int* part_cnt, int fsplits, int HW, int q, bool& fb,
+                                           int heavy_cap) {
+    fb = fsplits > 0 && ovf[q >> 6] != 0;
+    if (!fb) { const int t = gcnt[q]; return t > heavy_cap ? heavy_cap : t; }
     int t = 0;
     for (int s = 0; s < fsplits; ++s) t += part_cnt[(size_t)s * HW + q];
-    return t > AFM_HEAVY ? AFM_HEAVY : t;
+    return t > heavy_cap ? heavy_cap : t;
 }
 __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __restrict__ gcand, const int* __restrict__ gcnt,
                                                                const int* __restrict__ ovf, const u64* __restrict__ part_key,
                                                                const int* __restrict__ part_cnt, int fsplits, int HW, int top_k,
-                                                               float* __restrict__ out_w, int* __restrict__ out_idx,
+                                                               int heavy_cap, float* __restrict__ out_w, int* __restrict__ out_idx,
                                                                float* __restrict__ out_sim) {
     __shared__ __attribute__((aligned(16))) u64 s_keys[16][AFM_LIGHT + 2];
-    __shared__ __attribute__((aligned(16))) u64 s_heavy[4][AFM_HEAVY + 2];
+    extern __shared__ __attribute__((aligned(16))) u64 s_heavy_dyn[];        // [4][heavy_cap + 2]: the longest list a query can have
     __shared__ float s_v[16][AFF_MAX_TOPK];
     __shared__ int s_i[16][AFF_MAX_TOPK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __rest
     float* sv = s_v[g]; int* si = s_i[g];
     for (int r = l; r < top_k; r += 16) { sv[r] = -INFINITY; si[r] = 0; }     // never an out-of-range index, whatever happens upstream
     bool fb = false;
-    const int total = q < HW ? merge_count(gcnt, ovf, part_cnt, fsplits, HW, q, fb) : 0;
+    const int total = q < HW ? merge_count(gcnt, ovf, part_cnt, fsplits, HW, q, fb, heavy_cap) : 0;
     const bool light = q < HW && total <= AFM_LIGHT;
     if (light) {
         u64* keys = s_keys[g];
@@ -923,13 +924,13 @@ __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __rest
         const int qj = blockIdx.x * 16 + wv * 4 + j;
         if (qj >= HW || tj <= AFM_LIGHT) continue;
         const bool fbj = __shfl((int)fb, j * 16, 64) != 0;
-        u64* keys = s_heavy[wv];
+        u64* keys = s_heavy_dyn + (size_t)wv * (heavy_cap + 2);
         float* svj = s_v[wv * 4 + j]; int* sij = s_i[wv * 4 + j];
         int T = 0;
         if (fbj) {
-            for (int s = 0; s < fsplits && T < AFM_HEAVY; ++s) {
+            for (int s = 0; s < fsplits && T < heavy_cap; ++s) {
                 int c = part_cnt[(size_t)s * HW + qj];
-                if (T + c > AFM_HEAVY) c = AFM_HEAVY - T;
+                if (T + c > heavy_cap) c = heavy_cap - T;
                 for (int e = lane; e < c; e += 64) keys[T + e] = part_key[((size_t)s * HW + qj) * AFF_OUTCAP + e];
                 T += c;
             }
@@ -1187,8 +1188,10 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }
     // no overflow path: the lists of the wide kernel tighten themselves (see its episodes); the merge reads the global lists
-    hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), 0, s, gcand, gcnt, ovf, a.part_key, a.part_cnt,
-                       0, HW, top_k, out_w, out_idx, out_sim);
+    int heavy_cap = w.splits * (top_k > 32 ? top_k : 32);          // every workgroup hands over at most max(top_k, 32) entries
+    if (heavy_cap > AFW_GCAP) heavy_cap = AFW_GCAP;
+    hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), (size_t)4 * (heavy_cap + 2) * sizeof(u64), s, gcand, gcnt,
+                       ovf, a.part_key, a.part_cnt, 0, HW, top_k, heavy_cap, out_w, out_idx, out_sim);
     return xmem_check_launch();
 }
 
