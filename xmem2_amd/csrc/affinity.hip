@@ -23,6 +23,7 @@
 // Small memories (< 256 tiles) skip pass A (tau0 = -inf) and rely on the re-rank.
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 #define AFF_BQ 64          // queries per workgroup
 #define AFF_LDB 132        // LDS row stride of the query operand (floats)
