@@ -77,6 +77,8 @@ typedef struct {
     int res_broadcast;  /* 1: res is ONE image [Ho][Wo][ldres] added to every batch element (the per-object halves of the
                            fuser convolutions share the f16 half, model/modules.py:31-41 on cat([x, g])) */
     const void* w_winograd_f16; /* optional [16][Cout][Cin] IEEE half: the same G g G^T rounded to fp16 (plan_tile 16 only) */
+    const float* w_winograd4;   /* optional [36][Cout][Cin]: G g G^T of Winograd F(4x4,3x3) (plan_tile 17..22 = the GEMM tiles of
+                                   plans 7..12 inside the F(4x4) path; fp32, ~9e-6 of the output scale vs a fp64 convolution) */
 } xmem_conv_desc;
 
 size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);

@@ -86,7 +86,7 @@ def test_conv2d(case):
 
 
 @pytest.mark.parametrize('plan', [(1, 1), (2, 2), (3, 4), (4, 1), (5, 3), (6, 2), (7, 1), (9, 1), (10, 1), (12, 1),
-                                  (13, 1), (14, 1), (15, 1)])
+                                  (13, 1), (14, 1), (15, 1), (17, 1), (19, 1), (22, 1)])
 @pytest.mark.parametrize('shape', [(1, 30, 54, 256, 128), (2, 15, 27, 64, 96), (1, 17, 23, 32, 64)])
 def test_conv2d_every_plan(plan, shape):
     """Every tile / split-K / Winograd plan the autotuner may pick computes the same 3x3 convolution."""
@@ -105,6 +105,26 @@ def test_conv2d_every_plan(plan, shape):
     out = ops.conv2d(nhwc(x), cw, res=nhwc(res), relu_in=True, relu_out=True, plan=plan)
     torch.cuda.synchronize()
     close(nchw(out), ref, rtol=2e-4, atol=5e-5, msg=f'conv plan {plan} {shape}')
+
+
+def test_winograd_f4_accuracy_at_a_large_layer():
+    """F(4x4,3x3) is what the large 3x3 layers run by default: its error against a fp64 convolution stays ~1e-5 of the
+    output scale (F(2x2): ~5e-7), 20x inside the parity tolerance; odd sizes exercise the partial border tiles."""
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    gen = g_(5)
+    for (B, H, W, Cin, Cout) in [(1, 60, 108, 256, 256), (2, 61, 107, 64, 128)]:
+        x = F.relu(torch.randn(B, Cin, H, W, generator=gen))
+        w = torch.randn(Cout, Cin, 3, 3, generator=gen) * (2.0 / (Cin * 9)) ** 0.5
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+        cw = ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), torch.ones(Cout).cuda(), torch.zeros(Cout).cuda(), 1, 1)
+        scale = float(ref.abs().max())
+        errs = {}
+        for name, plan in (('direct', (3, 1)), ('F2', (9, 1)), ('F4', (19, 1)), ('default', None)):
+            out = nchw(ops.conv2d(nhwc(x), cw, plan=plan)).double()
+            errs[name] = float((out - ref).abs().max()) / scale
+        print(f'{(B, H, W, Cin, Cout)}: max err / scale {errs}')
+        assert errs['direct'] < 2e-6 and errs['F2'] < 5e-6 and errs['F4'] < 5e-5 and errs['default'] < 5e-5
 
 
 def test_conv2d_into_channel_slice_and_strided_input():

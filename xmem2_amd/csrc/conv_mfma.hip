@@ -566,6 +566,119 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(WinoArgs p) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// Winograd F(4x4, 3x3) for the LARGE 3x3 / stride 1 layers (plan_tile 17..22): 36 multiplies per 4x4 outputs instead of
+// 144 - 4x fewer MFMA FLOPs than the direct form (F(2x2): 2.25x) and 2.25 / 4 of F(2x2)'s transform-domain traffic
+// (36 values per 16 outputs instead of 16 per 4).  Interpolation points {0, +-1, +-2, inf}; all fp32; measured error vs a
+// fp64 convolution 9e-6 of the output scale (F(2x2): 5e-7, direct: 2e-7) - inside the 2e-4 parity tolerance, which is why
+// it is used only where it pays (>= 1/8 resolution) and F(2x2) elsewhere.
+//   V = B^T d B (6x6 input tile, stride 4), M_xi = V_xi U_xi^T on the same MFMA GEMM (36 groups), Y = A^T M A (4x4).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino4_bt(const f32x4* d, f32x4* t) {      // t = B^T d for one 6-vector
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void wino4_at(const f32x4* m, f32x4* s) {      // s = A^T m for one 6-vector
+    s[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    s[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+    s[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+    s[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ in, int ldin, int B, int H, int W, int C, int th, int tw,
+                                                          int relu_in, float* __restrict__ V) {
+    const int C4 = C >> 2;
+    const size_t P = (size_t)B * th * tw;
+    const size_t total = P * C4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        size_t t = e / C4;
+        const int tx = (int)(t % tw); size_t r = t / tw;
+        const int ty = (int)(r % th);
+        const int b = (int)(r / th);
+        f32x4 d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int ih = 4 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int iw = 4 * tx - 1 + j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * ldin + c4 * 4);
+                    if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                }
+                d[i][j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {              // columns: d[:, j] <- B^T d[:, j]
+            f32x4 col[6], tc[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+            wino4_bt(col, tc);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i][j] = tc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {              // rows: (B^T d) B, stored to the 36 position planes
+            f32x4 tr[6];
+            wino4_bt(d[i], tr);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(V + ((size_t)(i * 6 + j) * P + t) * C + c4 * 4) = tr[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mt, int B, int Ho, int Wo, int Cout, int th, int tw,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ res, int ldres, int res_bcast, int relu_out,
+                                                           float* __restrict__ out, int ldout) {
+    const int N4 = Cout >> 2;
+    const size_t P = (size_t)B * th * tw;
+    const size_t total = P * N4;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int n4 = (int)(e % N4);
+        size_t t = e / N4;
+        const int tx = (int)(t % tw); size_t r = t / tw;
+        const int ty = (int)(r % th);
+        const int b = (int)(r / th);
+        f32x4 s[4][6];                             // A^T m, column by column
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            f32x4 col[6], sc[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const f32x4*>(Mt + ((size_t)(i * 6 + j) * P + t) * Cout + n4 * 4);
+            wino4_at(col, sc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i][j] = sc[i];
+        }
+        const f32x4 scl = *reinterpret_cast<const f32x4*>(scale + n4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n4 * 4);
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            f32x4 y[4];
+            wino4_at(s[dy], y);
+            const int oh = 4 * ty + dy;
+            if (oh >= Ho) continue;
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int ow = 4 * tx + dx;
+                if (ow >= Wo) continue;
+                const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
+                f32x4 v = y[dx] * scl + sh;
+                if (res) v += *reinterpret_cast<const f32x4*>(res + (res_bcast ? (size_t)oh * Wo + ow : pix) * ldres + n4 * 4);
+                if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
 // REDUCED-PRECISION MODE (opt-in, plan_tile 16): the Winograd-domain operands V = B^T d B and U = G g G^T are stored in
 // fp16 and contracted on v_mfma_f32_32x32x16_f16 (fp32 accumulation, 16x the fp32 MFMA rate); transforms, epilogue and
 // every other kernel stay fp32.  Mirrors the reference's fp16-autocast GPU loop (inference/run_on_video.py:76); it is
@@ -731,7 +844,7 @@ __global__ __launch_bounds__(256) void wino_gemm_f16_kernel(WinoF16Args p) {
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; bool wino4; };
 
 inline bool wino_ok(const xmem_conv_desc* d) {
     return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
@@ -745,7 +858,7 @@ int validate(const xmem_conv_desc* d) {
     if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
     if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
     if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
-    if (d->plan_tile < 0 || d->plan_tile > 16 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
+    if (d->plan_tile < 0 || d->plan_tile > 22 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
     return XMEM_OK;
 }
 
@@ -764,11 +877,16 @@ Plan make_plan(const xmem_conv_desc* d) {
     pl.wino = false;
     pl.fused = 0;
     pl.f16 = false;
+    pl.wino4 = false;
     if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
     if (d->plan_tile > 0) {
         static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
         int t = d->plan_tile;
+        if (t >= 17) {                     // F(4x4, 3x3) with the GEMM tile of plan t - 10; F(2x2) when its operand is absent
+            if (wino_ok(d) && d->w_winograd4) pl.wino4 = true;
+            t -= 10;
+        }
         if (t == 16) {                     // reduced-precision Winograd (opt-in); falls back to the fp32 Winograd tile 64x64
             if (wino_ok(d) && d->w_winograd_f16 && d->Cin % 64 == 0) {
                 pl.wino = true; pl.f16 = true; pl.bm = 0; pl.bn = 0; pl.nk = d->Cin / 64; pl.splitk = 1; pl.kt_per_split = pl.nk;
@@ -848,6 +966,7 @@ extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
     if (validate(d) != XMEM_OK) return 0;
     Plan pl = make_plan(d);
     int Ho, Wo; out_dims(d, Ho, Wo);
+    if (pl.wino && pl.wino4) return (size_t)36 * d->B * cdiv(Ho, 4) * cdiv(Wo, 4) * (d->Cin + d->Cout) * sizeof(float);
     if (pl.wino && pl.f16) return align_up((size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cin * 2, 256) +
                                   (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cout * sizeof(float);
     if (pl.wino && pl.fused) return (size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cin * sizeof(float);
@@ -872,6 +991,35 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
     a.tiles_m = pl.bm ? cdiv(a.M, pl.bm) : 0; a.tiles_n = pl.bn ? cdiv(a.Cout, pl.bn) : 0;
     a.raw = 0; a.res_mod = d->res_broadcast ? Ho * Wo : 0; a.in_gstride = 0; a.w_gstride = 0; a.out_gstride = 0;
+    if (pl.wino && pl.wino4) {
+        const int th = cdiv(Ho, 4), tw = cdiv(Wo, 4);
+        const size_t P = (size_t)d->B * th * tw;
+        const size_t need = (size_t)36 * P * (d->Cin + d->Cout) * sizeof(float);
+        if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
+        if (P > 0x7fffffff) return XMEM_ERR_UNSUPPORTED;
+        float* V = reinterpret_cast<float*>(workspace);
+        float* Mt = V + (size_t)36 * P * d->Cin;
+        hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+        size_t tot = P * (d->Cin / 4);
+        int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wino4_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
+                           d->relu_in, V);
+        ConvArgs g = a;
+        g.in = V; g.w = d->w_winograd4; g.out = Mt; g.res = nullptr; g.partial = nullptr;
+        g.B = 1; g.H = 1; g.W = (int)P; g.ldin = d->Cin; g.Ho = 1; g.Wo = (int)P; g.ldout = d->Cout; g.ldres = 0;
+        g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.K = d->Cin; g.M = (int)P; g.HoWo = (int)P;
+        g.relu_in = 0; g.relu_out = 0; g.nk = pl.nk; g.splitk = 1; g.kt_per_split = pl.nk;
+        g.tiles_m = cdiv(g.M, pl.bm); g.tiles_n = cdiv(g.Cout, pl.bn);
+        g.raw = 1; g.in_gstride = (long)P * d->Cin; g.w_gstride = (long)d->Cout * d->Cin; g.out_gstride = (long)P * d->Cout;
+        rc = (pl.bk == 64) ? (pl.generic ? launch_bk<64, true>(pl, g, s, 36) : launch_bk<64, false>(pl, g, s, 36))
+                           : (pl.generic ? launch_bk<32, true>(pl, g, s, 36) : launch_bk<32, false>(pl, g, s, 36));
+        if (rc != XMEM_OK) return rc;
+        tot = P * (d->Cout / 4);
+        blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(blocks), dim3(256), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
+                           d->res, d->ldres, d->res_broadcast ? 1 : 0, d->relu_out, d->out, d->ldout);
+        return xmem_check_launch();
+    }
     if (pl.wino && pl.f16) {
         const int th = cdiv(Ho, 2), tw = cdiv(Wo, 2);
         const size_t P = (size_t)d->B * th * tw;

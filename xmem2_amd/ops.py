@@ -114,7 +114,7 @@ class precision:
 
 class ConvWeights:
     """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
-    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu', 'wu_f16')
+    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu', 'wu_f16', 'wu4')
 
     def __init__(self, w, scale, shift, stride, pad, cin_true=None, winograd=True):
         self.w, self.scale, self.shift = w, scale, shift
@@ -123,6 +123,7 @@ class ConvWeights:
         self.cin_true = cin_true if cin_true is not None else self.cin     # un-padded Cin (algorithmic FLOPs)
         self.wu = None
         self.wu_f16 = None
+        self.wu4 = None                  # F(4x4,3x3) operand, built on first use (only the large layers take that path)
         if winograd and self.kh == 3 and self.kw == 3 and stride == 1 and pad == 1 and self.cin % 32 == 0 \
                 and self.cout % 4 == 0 and self.cout >= 32:
             self.wu = winograd_weights(w)
@@ -131,6 +132,23 @@ class ConvWeights:
 
 
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+_WINO4_G = torch.tensor([[0.25, 0.0, 0.0], [-1.0 / 6, -1.0 / 6, -1.0 / 6], [-1.0 / 6, 1.0 / 6, -1.0 / 6],
+                         [1.0 / 24, 1.0 / 12, 1.0 / 6], [1.0 / 24, -1.0 / 12, 1.0 / 6], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def winograd4_weights(w):
+    """[Cout][3][3][Cin] -> G g G^T of F(4x4,3x3) as [36][Cout][Cin] (load-time, formed in fp64 and rounded once to fp32)."""
+    g = _WINO4_G.to(w.device)
+    u = torch.einsum('ia,nabc,jb->ijnc', g, w.double(), g)
+    return u.reshape(36, w.shape[0], w.shape[3]).to(torch.float32).contiguous()
+
+
+# F(4x4,3x3) replaces F(2x2,3x3) for outputs of at least this many pixels per image (1/8 resolution of 480p and up): below
+# that the 36 tile-position GEMMs are too small to fill the chip.  XMEM_WINO4=0 turns it off (F(2x2) everywhere).
+WINO4_MIN_PIXELS = int(os.environ.get('XMEM_WINO4_MIN_PIXELS', '4096'))
+WINO4 = os.environ.get('XMEM_WINO4', '1') != '0'
 
 
 def winograd_weights(w):
@@ -239,6 +257,7 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     d.res_broadcast = int(bool(res_broadcast and res is not None))   # res [1,Ho,Wo,C] added to every batch element
     d.out = out.data_ptr(); d.ldout = out_ld
     d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    explicit = plan is not None                  # a caller-given plan is taken literally (tests, the tuner)
     d.w_winograd = cw.wu.data_ptr() if cw.wu is not None else None
     d.w_winograd_f16 = None
     if _PRECISION == 'fp16' and cw.wu_f16 is not None and plan is None and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0):
@@ -252,6 +271,18 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
             plan = _tune_conv(lib, d, x.device)
         _tuned_now[key] = plan
+    d.w_winograd4 = None
+    if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32':
+        if cw.wu4 is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('conv2d: the F(4x4) operand must be built before graph capture (run the stage eagerly once)')
+            cw.wu4 = winograd4_weights(cw.w)
+        d.w_winograd4 = cw.wu4.data_ptr()
+        plan = (plan[0] + 10, plan[1])
+    elif 17 <= plan[0] <= 22:
+        if cw.wu4 is None and cw.wu is not None:
+            cw.wu4 = winograd4_weights(cw.w)
+        d.w_winograd4 = cw.wu4.data_ptr() if cw.wu4 is not None else None
     d.plan_tile, d.plan_splitk = plan
     need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
     ws = workspace(need, x.device, 'conv') if need else None
