@@ -233,7 +233,7 @@ def run_gpu(args, device, rank, world):
 
 
 # ---- rocprofv3 kernel trace of the timed region (child process) ------------------------------------------------
-FAMILIES = (('conv', ('conv_', 'wino_')),
+FAMILIES = (('conv', ('conv_', 'wino_', 'wino4_')),
             ('affinity', ('affinity_',)),
             ('readout', ('readout_sparse_kernel',)),
             ('usage', ('usage_',)),

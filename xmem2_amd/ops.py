@@ -147,7 +147,7 @@ def winograd4_weights(w):
 
 # F(4x4,3x3) replaces F(2x2,3x3) for outputs of at least this many pixels per image (1/8 resolution of 480p and up): below
 # that the 36 tile-position GEMMs are too small to fill the chip.  XMEM_WINO4=0 turns it off (F(2x2) everywhere).
-WINO4_MIN_PIXELS = int(os.environ.get('XMEM_WINO4_MIN_PIXELS', '4096'))
+WINO4_MIN_PIXELS = int(os.environ.get('XMEM_WINO4_MIN_PIXELS', '4096'))   # applies to F(2x2) entries of the plan table only
 WINO4 = os.environ.get('XMEM_WINO4', '1') != '0'
 
 
@@ -185,12 +185,14 @@ def dump_tuned_plans(path):
     """Write every plan known to this process (shipped + tuned now) - used to refresh conv_plans.json."""
     allp = dict(_load_plans())
     allp.update(_tuned_now)
+    if WINO4:
+        allp['__tuned_with_f4__'] = (1, 0)           # every entry was measured against the F(4x4) candidates too
     with open(path, 'w') as f:
         json.dump({k: list(v) for k, v in sorted(allp.items())}, f, indent=0)
     return len(allp)
 
 
-def _tune_conv(lib, d, x_device):
+def _tune_conv(lib, d, x_device, cw=None):
     """Time the candidate (tile, split-K) plans for this descriptor; returns the fastest."""
     Ho = (d.H + 2 * d.pad - d.KH) // d.stride + 1
     Wo = (d.W + 2 * d.pad - d.KW) // d.stride + 1
@@ -201,12 +203,19 @@ def _tune_conv(lib, d, x_device):
     if d.w_winograd and d.ldout % 4 == 0 and (not d.res or d.ldres % 4 == 0):
         cands += [(t + 6, cfg) for t, cfg in tiles.items()]
         cands += [(13, (128, 64, 32)), (14, (64, 64, 32)), (15, (64, 128, 32))]
+        if cw is not None and WINO4 and Ho * Wo >= 256:          # F(4x4,3x3): the same GEMM tiles over 36 positions
+            if cw.wu4 is None:
+                cw.wu4 = winograd4_weights(cw.w)
+            d.w_winograd4 = cw.wu4.data_ptr()
+            cands += [(t + 16, cfg) for t, cfg in tiles.items()]
     for tile, (bm, bn, bk) in cands:
         if bn == 128 and d.Cout <= 64 and tile != 15:
             continue
         nt = -(-M // bm) * -(-d.Cout // bn)
         nk = -(-K // bk)
         for sk in ((1,) if tile > 6 else (1, 2, 3, 4, 6, 8, 12, 16)):
+            if tile > 16 and nt * 36 < 128:
+                continue
             if sk > 1 and (nt * sk > 2048 or nk // sk < 2):
                 continue
             if sk == 1 and nt < 48 and nk >= 16:
@@ -269,10 +278,11 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     if plan is None:
         plan = (0, 0)
         if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
-            plan = _tune_conv(lib, d, x.device)
+            plan = _tune_conv(lib, d, x.device, cw)
         _tuned_now[key] = plan
     d.w_winograd4 = None
-    if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32':
+    if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32' \
+            and '__tuned_with_f4__' not in _load_plans():      # a table tuned against F(4x4) already says which layers take it
         if cw.wu4 is None:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('conv2d: the F(4x4) operand must be built before graph capture (run the stage eagerly once)')
