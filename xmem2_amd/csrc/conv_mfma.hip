@@ -260,180 +260,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     }
 }
 
-// Persistent form of the ONE path (pointwise layers and the 16 / 36 Winograd-position GEMMs; no split-K): these GEMMs
-// have SHORT K loops (8 k-tiles at Cin = 256), so with one workgroup per output tile a CU slot spent a third of its life in
-// dispatch + the exposed first load + the epilogue.  Here a fixed grid of workgroups walks the (group, M-tile, N-tile) list
-// and the first k-tile of the NEXT output tile is loaded under the last k-tile's MFMAs of the current one - the matrix pipe
-// sees one continuous K loop.  Tile order keeps the XCD-aware mapping (a round of gridDim.x tiles, bijectively swizzled).
-template <int BM, int BN, int TM, int TN, int BK>
-__global__ __launch_bounds__(256) void conv_gemm_persist_kernel(ConvArgs p, int groups) {
-    constexpr int WN = BN / (32 * TN);
-    constexpr int WM = BM / (32 * TM);
-    static_assert(WM * WN == 4, "four waves per workgroup");
-    constexpr int LDK = BK + 4;
-    constexpr int C4 = BK / 4;
-    constexpr int RPP = 256 / C4;
-    constexpr int RA = BM / RPP, RB = BN / RPP;
-    constexpr int BUF = (BM + BN) * LDK;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int lrow = tid / C4, c4 = tid % C4;
-    const int per_group = p.tiles_m * p.tiles_n;
-    const int total = per_group * groups;
-    const int nwg = gridDim.x;                        // multiple of 8
-    const int slot = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);      // XCD x owns a contiguous eighth of every round
-
-    unsigned a_boff[RA], b_boff[RB];
-    const char* abase; const char* bbase;
-    int m0 = 0, n0 = 0, grp = 0;
-    auto setup = [&](int t) {                          // tile t -> operand row offsets of this thread
-        grp = t / per_group;
-        const int r = t - grp * per_group;
-        const int tile_n = r % p.tiles_n, tile_m = r / p.tiles_n;
-        m0 = tile_m * BM; n0 = tile_n * BN;
-        abase = reinterpret_cast<const char*>(p.in + (size_t)grp * p.in_gstride);
-        bbase = reinterpret_cast<const char*>(p.w + (size_t)grp * p.w_gstride);
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int m = min(m0 + lrow + RPP * i, p.M - 1);
-            unsigned pix = (unsigned)m;
-            if (p.stride != 1) {
-                const int b = m / p.HoWo, rem = m - b * p.HoWo;
-                const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-                pix = (unsigned)((b * p.H + oh * p.stride) * p.W + ow * p.stride);
-            }
-            a_boff[i] = (pix * (unsigned)p.ldin + (unsigned)(c4 * 4)) * 4u;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int n = min(n0 + lrow + RPP * i, p.Cout - 1);
-            b_boff[i] = ((unsigned)n * (unsigned)p.K + (unsigned)(c4 * 4)) * 4u;
-        }
-    };
-    f32x4 ra[RA], rb[RB];
-    auto load_tile = [&](int kt) {
-        const size_t kb = (size_t)kt * BK * 4;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + kb + a_boff[i]);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bbase + kb + b_boff[i]);
-    };
-    auto store_tile = [&](int buf) {
-        float* As = smem + buf * BUF;
-        float* Bs = As + BM * LDK;
-        if (p.relu_in) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
-                ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * LDK + c4 * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + RPP * i) * LDK + c4 * 4]) = rb[i];
-    };
-
-    int t = slot;
-    if (t >= total) return;
-    setup(t);
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    int buf = 0;
-    const int nk = p.nk;
-    while (t < total) {
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int cm0 = m0, cn0 = n0, cgrp = grp;      // the tile being accumulated (setup() moves on to the next one below)
-        const int tnext = t + nwg;
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool last = kt + 1 == nk;
-            const bool more = !last || tnext < total;
-            if (!last) load_tile(kt + 1);
-            else if (tnext < total) { setup(tnext); load_tile(0); }       // next output tile's first k-tile under these MFMAs
-            const float* As = smem + buf * BUF + (wm * 32 * TM + l31) * LDK + lh * 4;
-            const float* Bs = smem + buf * BUF + BM * LDK + (wn * 32 * TN + l31) * LDK + lh * 4;
-            f32x4 af[2][TM], bf[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK);
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                const int cur = kk & 1, nxt = cur ^ 1;
-                if (kk + 1 < BK / 8) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af[nxt][i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDK + (kk + 1) * 8);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + (kk + 1) * 8);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int sx = 0; sx < 4; ++sx)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][sx], bf[cur][j][sx], acc[i][j], 0, 0, 0);
-            }
-            if (more) store_tile(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-        }
-        // epilogue of the finished tile (the next tile's first k-tile is already in LDS)
-        const int mode = p.raw ? 0 : (p.res ? 3 : 2);
-        float* const gout = p.out + (size_t)cgrp * p.out_gstride;
-        const long ldo = (long)p.ldout;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = cn0 + wn * 32 * TN + j * 32 + l31;
-            if (n >= p.Cout) continue;
-            float sc = 1.f, sh = 0.f;
-            if (mode >= 2) { sc = p.scale[n]; sh = p.shift[n]; }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int mb = cm0 + wm * 32 * TM + i * 32 + 4 * lh;
-                float* const orow = gout + (size_t)mb * ldo + n;
-                float rv[16];
-                if (mode == 3) {
-                    int mr = p.res_mod ? mb % p.res_mod : mb;
-                    const bool wrap_ok = p.res_mod >= 32;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int o = (r & 3) + 8 * (r >> 2);
-                        int tt = mr + o;
-                        if (p.res_mod) { if (wrap_ok) { if (tt >= p.res_mod) tt -= p.res_mod; } else tt = (mb + o) % p.res_mod; }
-                        rv[r] = (mb + o < p.M) ? p.res[(size_t)tt * p.ldres + n] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = (r & 3) + 8 * (r >> 2);
-                    if (mb + o >= p.M) continue;
-                    float v = acc[i][j][r];
-                    if (mode >= 2) {
-                        v = v * sc + sh;
-                        if (mode == 3) v += rv[r];
-                        if (p.relu_out) v = fmaxf(v, 0.f);
-                    }
-                    orow[(long)o * ldo] = v;
-                }
-            }
-        }
-        t = tnext;
-    }
-}
-
 __global__ void conv_splitk_reduce_kernel(ConvArgs p) {
     const size_t total = (size_t)p.M * p.Cout;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -1113,29 +939,9 @@ static bool conv_is_one(const ConvArgs& a) {
            (double)a.B * a.H * a.W * a.ldin * 4.0 < 4.0e9 && (double)a.Cout * a.K * 4.0 < 4.0e9;
 }
 
-// persistent GEMM for the ONE path (XMEM_CONV_PERSIST=0 restores one workgroup per output tile)
-static bool conv_persist() {
-    static const int off = getenv("XMEM_CONV_PERSIST") && getenv("XMEM_CONV_PERSIST")[0] == '0';
-    return !off;
-}
-
 template <int BM, int BN, int TM, int TN, int BK, bool G>
 int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1) {
     const size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    if (!G && conv_is_one(a) && a.splitk == 1 && conv_persist()) {
-        const long total = (long)a.tiles_m * a.tiles_n * groups;
-        // resident workgroups: LDS lets 160 KB / lds of them share a CU (at most 4); fewer tiles than that -> one round
-        int per_cu = (int)((160 * 1024) / lds); if (per_cu > 4) per_cu = 4; if (per_cu < 1) per_cu = 1;
-        long g = 256L * per_cu;
-        if (g > total) g = (total + 7) / 8 * 8;
-        auto pk = conv_gemm_persist_kernel<BM, BN, TM, TN, BK>;
-        if (lds > 64 * 1024) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
-        }
-        hipLaunchKernelGGL(pk, dim3((unsigned)g), dim3(256), lds, s, a, groups);
-        return xmem_check_launch();
-    }
     auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false>;
     if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true>;
     if (lds > 64 * 1024) {
