@@ -43,6 +43,7 @@ class XMem:
         self._stages = {}
         self._zeros = {}
         self._call_precision = None      # per-call override (InferenceCore preloads permanent memory in fp32)
+        self.max_stages = int(os.environ.get('XMEM_MAX_STAGES', '160'))   # captured HIP-graph stages kept before the cache is dropped
         # the decoder's skip convolutions depend only on f8 / f4: inside the captured key-encoder graph they run on a
         # forked stream next to the small-grid layer2 / layer3 kernels.  Measured neutral on MI355X (A/B on one box:
         # 272 vs 273 fps), so it is off by default (XMEM_OVERLAP=1 enables it).
@@ -254,6 +255,11 @@ class XMem:
                 with torch.cuda.graph(graph):
                     static_out = fn(*static_in)
             st = (graph, static_in, static_out)
+            if len(self._stages) >= self.max_stages:
+                # bound the cache: every resolution / object count / slot adds graphs with private pools.  Stages alias each
+                # other's static buffers (the decoder reads the key encoder's outputs in place), so the whole cache goes
+                # together; everything is re-captured on demand.
+                self._stages.clear()
             self._stages[full_key] = st
         graph, static_in, static_out = st
         for dst, src in zip(static_in, inputs):
@@ -346,7 +352,8 @@ class XMem:
         overlap = bool(with_skips and not inline_skips and self.overlap_skips and self.use_graphs and not ops.eager_only()
                        and image4.shape[0] == 1)
         inline = bool(with_skips and inline_skips)      # a prefetched pass also runs the decoder's skip convolutions
-        ops._ws_suffix = f'@key{slot}'      # key-encoder graphs may run on a side stream: never share scratch with the decoder
+        # key-encoder graphs may run on a side stream: never share scratch with the decoder, nor with another network instance
+        ops._ws_suffix = f'@key{slot}@{id(self):x}'
         try:
             out = self._run_stage('key', (need_sk, need_ek, overlap, inline, slot), [image4],
                                   lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap, inline))

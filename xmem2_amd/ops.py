@@ -71,7 +71,10 @@ def time_recorded(records, reps=10):
 
 
 def workspace(nbytes, device, tag='default'):
-    """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so reuse is safe."""
+    """Grow-only scratch buffer per (device, tag + scope suffix); kernels on one stream run in order so reuse is safe.
+    The scope suffix (`_ws_suffix`, set by XMem around its side-stream key-encoder stages, unique per network instance and
+    graph slot) keeps concurrently running streams on separate scratch.  The module is single-threaded by contract (as the
+    reference's InferenceCore): two host threads driving kernels at once are not supported."""
     key = (str(device), tag + _ws_suffix)      # kernels on a side stream get their own scratch
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
