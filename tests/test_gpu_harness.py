@@ -191,3 +191,39 @@ def test_remove_from_permanent_memory_core_vs_oracle(hip_net, ref_net):
         check(f'after removing {idx}')
     with pytest.raises(KeyError):
         core.remove_from_permanent_memory(3)
+
+
+def test_launcher_runs_videos_on_this_gpu(checkpoint, tmp_path):
+    """xmem2_amd.launch end to end on the box's GPU(s): two chair sub-clips dealt to `--gpus 1` worker(s), real run_on_video,
+    masks written per video, summary merged; the longer video goes first.  (World size 2 and the refusal paths run on CPU in
+    tests/test_multi_gpu.py.)"""
+    import json
+    import subprocess
+    import sys
+    names = sorted(os.listdir(os.path.join(CHAIR, 'JPEGImages')))
+    for vid, sel in (('short', names[:4]), ('long', names[:7])):
+        for sub, ext in (('JPEGImages', '.jpg'), ('Annotations', '.png')):
+            d = tmp_path / sub / vid
+            d.mkdir(parents=True)
+            for n in sel:
+                os.symlink(os.path.join(CHAIR, sub, n[:-4] + ext), d / (n[:-4] + ext))
+    out = tmp_path / 'out'
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    cmd = [sys.executable, '-m', 'xmem2_amd.launch', '--gpus', '1', '--videos', str(tmp_path / 'JPEGImages'),
+           '--masks', str(tmp_path / 'Annotations'), '--out', str(out), '--frames-with-masks', '0', '--compute-iou',
+           '--config', json.dumps({'model': checkpoint, 'size': -1})]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    summ = json.load(open(out / 'summary.json'))
+    assert summ['n_gpus'] == 1 and summ['total_frames'] == 11 and not summ['ranks_missing']
+    assert [v['name'] for v in summ['videos']] == ['long', 'short'] and all(v['rank'] == 0 for v in summ['videos'])
+    assert len(os.listdir(out / 'long' / 'masks')) == 7 and len(os.listdir(out / 'short' / 'masks')) == 4
+    # same masks as a direct run_on_video call on the same files
+    from xmem2_amd.run_on_video import run_on_video
+    run_on_video(str(tmp_path / 'JPEGImages' / 'short'), str(tmp_path / 'Annotations' / 'short'), str(tmp_path / 'direct'),
+                 frames_with_masks=[0], print_progress=False, overwrite_config={'model': checkpoint, 'size': -1})
+    ref_png = os.path.join(CHAIR, 'Annotations', names[0][:-4] + '.png')
+    a = _read_written_masks(str(out / 'short'), names[:4], ref_png)
+    b = _read_written_masks(str(tmp_path / 'direct'), names[:4], ref_png)
+    assert np.array_equal(a, b)
