@@ -605,16 +605,16 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
     };
     auto episode = [&]() -> bool {                    // every wave of the workgroup calls this the same number of times
         __syncthreads();
-        const bool f = *flag != 0;
-        if (f) {
+        const bool f = *flag != 0;                    // uniform: the flag is only cleared after the second barrier, which no
+        if (f) {                                      // wave can pass before every wave has read it here
             for (int q = wave; q < AFW_BQ; q += AFW_WAVES) {
                 int c = cnt[q];
                 c = c > AFW_CAP ? AFW_CAP : c;
                 if (c > keep) compact(q, c);
             }
-            if (tid == 0) *flag = 0;
             __syncthreads();
-        }
+            if (tid == 0) *flag = 0;                  // a flag raised again this early could be lost: harmless, that wave's next
+        }                                             // attempt fails again and raises it again (a retry is >= one full tile away)
         return f;
     };
 
