@@ -430,12 +430,15 @@ def test_affinity_optimistic_overflow_falls_back_exactly():
     close(dense, aff.t(), 2e-4, 1e-7, 'affinity after fallback')
 
 
-def test_affinity_hint_never_changes_the_result():
+@pytest.mark.parametrize('filter16', ['1', '0'])
+def test_affinity_hint_never_changes_the_result(filter16, monkeypatch):
     """xmem_affinity_topk_hinted: the hint (previous top-k indices) only bounds the k-th similarity from below.  Results
     with a perfect hint, a hint from a DIFFERENT segment layout, a hint of k' > k indices, a garbage hint (all zeros:
-    fewer than k distinct elements -> no bound -> safe kernel) and a misleading hint (the WORST elements: a very loose bound
-    -> candidate lists overflow -> safe kernel) must all equal the un-hinted result."""
+    fewer than k distinct elements -> no bound -> full exact scan) and a misleading hint (the WORST elements: a very loose
+    bound -> candidate lists overflow -> self-tightening lists / full exact scan) must all equal the un-hinted result BIT FOR
+    BIT - with the fp16-filter + exact-refine pipeline (default for hinted calls) and with the fp32 select (FILTER16=0)."""
     from xmem2_amd import ops
+    monkeypatch.setenv('XMEM_AFFINITY_FILTER16', filter16)
     gen = g_(91)
     n, hw, gw = 20000, 300, 20
     mk = torch.randn(n, 64, generator=gen) * 0.9
@@ -463,6 +466,41 @@ def test_affinity_hint_never_changes_the_result():
         torch.cuda.synchronize()
         assert torch.equal(sv, s0), f'{name}: similarities differ from the un-hinted call'
         assert torch.equal(i, i0) and torch.equal(w, w0), f'{name}: indices / weights differ from the un-hinted call'
+
+
+@pytest.mark.parametrize('case', ['fp16 overflow', 'fp16 subnormal', 'huge shrinkage', 'ties', 'no selection'])
+def test_affinity_filter16_is_exact_on_hostile_values(case):
+    """The fp16 filter may only DROP a pair when a rigorous bound proves it is outside the top-k.  Values beyond the fp16 range
+    (x^2 > 65504), in its subnormal range (x^2 ~ 1e-6), shrinkages that blow the bound up, and exact ties (every element a
+    candidate) must still give the un-hinted fp32 result bit for bit."""
+    from xmem2_amd import ops
+    gen = g_(93)
+    n, hw, gw, k = 12000, 260, 20, 30
+    mk = torch.randn(n, 64, generator=gen) * 0.9
+    ms = torch.rand(n, generator=gen) * 3 + 1
+    qk = torch.randn(hw, 64, generator=gen) * 0.9
+    qe = torch.rand(hw, 64, generator=gen) * 0.9 + 0.05
+    if case == 'fp16 overflow':
+        mk[::7] *= 400.0                                           # x^2 up to ~1e6: inf in fp16
+        qk[::5] *= 300.0
+    elif case == 'fp16 subnormal':
+        mk *= 1e-3; qk *= 1e-3; qe *= 1e-2
+    elif case == 'huge shrinkage':
+        ms[::11] = 5e4
+    elif case == 'ties':
+        mk[:] = mk[:40].repeat(n // 40, 1)                          # 300 copies of 40 rows: every query has 300-fold ties
+        ms[:] = 2.0
+    qe_arg = None if case == 'no selection' else qe.cuda()
+    segs = [(mk[:5000].cuda(), ms[:5000].cuda()), (mk[5000:].cuda(), ms[5000:].cuda())]
+    sizes = [5000, n - 5000]
+    w0, i0, s0 = ops.affinity_topk(segs, qk.cuda(), qe_arg, k, want_sim=True)
+    for name, h in {'perfect': (i0, sizes, gw), 'shifted': (torch.roll(i0, 1, 0).contiguous(), sizes, 0)}.items():
+        w, i, sv = ops.affinity_topk(segs, qk.cuda(), qe_arg, k, want_sim=True, hint=h)
+        torch.cuda.synchronize()
+        assert torch.equal(sv, s0), f'{case} / {name}: similarities differ from the un-hinted call'
+        assert torch.equal(i, i0), f'{case} / {name}: indices differ'
+        same = torch.equal(w, w0) or bool(((w == w0) | (torch.isnan(w) & torch.isnan(w0))).all())
+        assert same, f'{case} / {name}: weights differ'
 
 
 # ---------------------------------------------------------------------------------------------------------

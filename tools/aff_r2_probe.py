@@ -24,7 +24,7 @@ def ws_views():
     ws = ops._workspaces[(str(qs[0][0].device), 'affinity')]
     a = lambda v, al=256: (v + al - 1) // al * al
     cnt_off = a(64 * HW * 88 * 8); bound_off = cnt_off + a(64 * HW * 4); tau_off = bound_off + a(64 * HW * 8 * 4)
-    ovf_off = tau_off + a(HW * 4); gcand_off = ovf_off + a(((HW + 63) // 64) * 4); gcnt_off = gcand_off + a(HW * 1024 * 8)
+    ovf_off = tau_off + a(HW * 4); gcand_off = ovf_off + a(((HW + 63) // 64) * 4); gcnt_off = gcand_off + a(HW * 2048 * 8)
     return (ws[tau_off:tau_off + HW * 4].view(torch.float32), ws[ovf_off:ovf_off + ((HW + 63) // 64) * 4].view(torch.int32),
             ws[gcnt_off:gcnt_off + HW * 4].view(torch.int32))
 def timeit(fn, reps=20):
@@ -45,6 +45,14 @@ for f, (qk, qe) in enumerate(qs[:NF]):
         tau, ovf, gcnt = ws_views()
         kth = sim[:, -1]
         t = timeit(lambda: ops.affinity_topk(segs, qk, qe, 30, hint=hint), 10)
+        if mode == 'hint' and f < 4:
+            mkr, msr = perm.key_rows(), perm.shrinkage_rows()
+            An = (mkr ** 4).sum(1).sqrt(); Bn = (mkr ** 2).sum(1).sqrt()
+            C = (qe ** 2).sum(1).sqrt(); D = ((2 * qk * qe) ** 2).sum(1).sqrt()
+            print(f'   rows: An mean {float(An.mean()):.2f} max {float(An.max()):.2f}  Bn mean {float(Bn.mean()):.2f} max {float(Bn.max()):.2f}  ms mean {float(msr.mean()):.2f} max {float(msr.max()):.2f}')
+            print(f'   queries: C mean {float(C.mean()):.2f} max {float(C.max()):.2f}  D mean {float(D.mean()):.2f} max {float(D.max()):.2f}')
+            eps = ((An * C[:128].max() + Bn * D[:128].max()) * 1.07e-3) * msr / 8
+            print(f'   eps (query tile 0): mean {float(eps.mean()):.4f} max {float(eps.max()):.4f};  gcnt hist: >2048: {int((gcnt > 2048).sum())}  >256: {int((gcnt > 256).sum())} >128: {int((gcnt > 128).sum())} median {float(gcnt.float().median()):.0f}')
         if f < 6 or f % 8 == 0 or int(ovf.sum()) > 0:
             print(f'frame {f:2d} {mode:10s}: {t:6.1f} us; tau0 gap to true k-th: mean {float((kth - tau).mean()):.3f} max {float((kth - tau).max()):.3f} '
                   f'(k-th mean {float(kth.mean()):.2f}, top1-kth {float((sim[:, 0] - kth).mean()):.2f}); candidates/query mean {float(gcnt.float().mean()):.1f} '

@@ -9,7 +9,8 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'consolidate.hip', 'selector.hip']
+SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'affinity_filter.hip', 'consolidate.hip', 'selector.hip']
+HEADERS = ['common.hpp', 'affinity_common.hpp']
 LIB = os.path.join(CSRC, 'libxmem_hip.so')
 ARCH = 'gfx950'
 
@@ -25,7 +26,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ['common.hpp']]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     deps.append(os.path.join(os.path.dirname(CSRC), '..', 'include', 'xmem_hip.h'))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -34,7 +35,7 @@ def source_digest():
     """sha256 over the kernel sources + header: profiles recorded for one build are only quoted against the same build."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(SOURCES + ['common.hpp']):
+    for f in sorted(SOURCES + HEADERS):
         with open(os.path.join(CSRC, f), 'rb') as fh:
             h.update(fh.read())
     with open(os.path.join(os.path.dirname(CSRC), '..', 'include', 'xmem_hip.h'), 'rb') as fh:

@@ -21,24 +21,17 @@
 //   merge: one wave per query ranks the surviving candidates of all splits, emits the sorted top-k and the
 //           softmax exp(v)/sum exp(v) (no max shift, memory_util.py:48-49).
 // Small memories (< 256 tiles) skip pass A (tau0 = -inf) and rely on the re-rank.
-#include "common.hpp"
-#include <math.h>
+#include "affinity_common.hpp"
 #include <stdlib.h>
 
 #define AFF_BQ 64          // queries per workgroup
 #define AFF_LDB 132        // LDS row stride of the query operand (floats)
-#define AFF_ROWS 32        // memory rows per wave tile
 #define AFF_STEP_ROWS 128  // rows per step (4 waves)
 #define AFF_MAXU 4         // candidate entries per lane during a re-rank (cap <= 256)
 #define AFF_OUTCAP 88      // candidates a (split, query) hands to the merge kernel
-#define AFF_MAX_TOPK 64
 #define AFF_BOUND_M 1      // survivors per lane and query in the bound pass
 #define AFF_BOUND_SLOTS (8 * AFF_BOUND_M)   // per (split, query): 4 waves x 2 half-waves x M
 #define AFF_MAX_BOUND_SPLITS 64
-
-typedef unsigned long long u64;
-
-struct SegDev { const float* key; const float* shr; int n; int base; int tile0; int pad; };
 
 struct AffArgs {
     SegDev seg[XMEM_MAX_SEGMENTS];
@@ -57,17 +50,6 @@ struct AffArgs {
     int* ovf;                        // [query tiles] overflow flags of the optimistic select pass
     u64* cand_spill;                 // MODE 3: [splits][query tiles][64][cap] global candidate buffers
 };
-
-__device__ __forceinline__ unsigned f2ord(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) {
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
-__device__ __forceinline__ u64 pack_key(float v, int idx) { return ((u64)f2ord(v) << 32) | (u64)(0xffffffffu - (unsigned)idx); }
-__device__ __forceinline__ float key_val(u64 k) { return ord2f((unsigned)(k >> 32)); }
-__device__ __forceinline__ int key_idx(u64 k) { return (int)(0xffffffffu - (unsigned)k); }
 
 // exact re-rank of one query's buffer by counting: larger key first (value, then lower index); keeps top_k sorted
 __device__ __forceinline__ void rerank(u64* ck, int c, int top_k, float* tau_q, int* cnt_q, int lane) {
@@ -139,7 +121,7 @@ __device__ __forceinline__ void affinity_body(const AffArgs& p, const int bx, co
                 const float e = eq ? eq[c] : 1.f;
                 row[part * 16 + c] = -e;
                 row[CK + part * 16 + c] = 2.f * (k * e);
-                bs += e * (k * k);
+                bs = bsq_term(bs, e, k);
             }
         } else {
 #pragma unroll
@@ -490,7 +472,6 @@ __global__ void affinity_merge_kernel(const u64* __restrict__ part_key, const in
 #define AFW_BQ 128
 #define AFW_WAVES 8
 #define AFW_CAP 80          // per (workgroup, query) LDS candidates
-#define AFW_GCAP 2048       // per-query global candidate list: <= 32 splits x max(top_k, 32) entries each
 
 struct WideArgs {
     SegDev seg[XMEM_MAX_SEGMENTS];
@@ -533,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
                 const float e = eq ? eq[c] : 1.f;
                 row[part * 16 + c] = -e;
                 row[CK + part * 16 + c] = 2.f * (k * e);
-                bs += e * (k * k);
+                bs = bsq_term(bs, e, k);
             }
         } else {
 #pragma unroll
@@ -754,6 +735,7 @@ struct HintArgs {
     const int* hint_idx; int hint_k; int grid_w;
     const float* qk; const float* qe; int HW, top_k;
     float* tau0; int* gcnt; int* ovf;
+    _Float16* qop16; float* qmeta;       // optional: query operands of the fp16 filter (affinity_filter.hip)
 };
 #define HINT_MAXC 320       // 5 queries x 64 indices
 #define HINT_NB 12          // entries taken from each grid neighbour's list
@@ -773,6 +755,29 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         const float e = p.qe ? p.qe[(size_t)q * CK + lane] : 1.f;
         op[lane] = -e; op[CK + lane] = 2.f * (k * e);
         bs = p.qe ? e * (k * k) : 0.f;
+    }
+    if (p.qop16) {
+        // operands of the fp16 filter, once per call: fp16 (-e | 2ke), b_sq exactly as the select kernels stage it (four parts
+        // of 16 sequential terms, then the pairwise tree), and the two operand norms (rounded up)
+        const float k = p.qk[(size_t)q * CK + lane];
+        const float e = p.qe ? p.qe[(size_t)q * CK + lane] : 1.f;
+        const float ke2 = 2.f * (k * e);
+        p.qop16[(size_t)q * 2 * CK + lane] = (_Float16)(-e);
+        p.qop16[(size_t)q * 2 * CK + CK + lane] = (_Float16)ke2;
+        const float sC = wave_sum(e * e), sD = wave_sum(ke2 * ke2);
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float kc = __shfl(k, 16 * (lane & 3) + c, 64), ec = __shfl(e, 16 * (lane & 3) + c, 64);
+            part = bsq_term(part, ec, kc);
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (lane == 0) {
+            f32x4 m;
+            m[0] = p.qe ? part : 0.f; m[1] = sqrtf(sC) * 1.0001f; m[2] = sqrtf(sD) * 1.0001f; m[3] = 0.f;
+            *reinterpret_cast<f32x4*>(p.qmeta + (size_t)q * 4) = m;
+        }
     }
     bs = wave_sum(bs);
 #pragma unroll
@@ -1049,11 +1054,17 @@ inline int bound_stride(int total_tiles) {
     return total_tiles >= 256 ? 4 : 1;
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, total; int fsplits; };
+// XMEM_AFFINITY_FILTER16=0 keeps hinted calls on the fp32 select (A/B measurements, tests of both pipelines)
+inline bool aff_use_filter16() {
+    const char* e = getenv("XMEM_AFFINITY_FILTER16");
+    return !(e && e[0] == '0');
+}
+
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
 #define AFF_FB_GRID 128     // persistent workgroups of the safe fallback pass (a scene cut flags every tile: ~0.7 ms at B32)
 inline int fallback_splits(int HW) { (void)HW; return 16; }
-WsLayout ws_layout(int HW) {
+WsLayout ws_layout(int HW, int n_total) {
     WsLayout w;
     w.fsplits = fallback_splits(HW);
     w.key_off = 0;                                                     // [<= 64 splits][HW][AFF_OUTCAP] (MODE 2 / MODE 3 lists)
@@ -1065,14 +1076,18 @@ WsLayout ws_layout(int HW) {
     w.gcnt_off = w.gcand_off + align_up((size_t)HW * AFW_GCAP * sizeof(u64), 256);
     w.spill_off = w.gcnt_off + align_up((size_t)HW * sizeof(int), 256);
     // fallback buffers: one per persistent workgroup, cap = 96 + 128
-    w.total = w.spill_off + (size_t)AFF_FB_GRID * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64);
+    w.qop16_off = w.spill_off + align_up((size_t)AFF_FB_GRID * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64), 256);
+    // fp16 filter: query operands, per-query meta, candidate bit matrix
+    w.qmeta_off = w.qop16_off + align_up((size_t)HW * 128 * sizeof(_Float16), 256);
+    w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
+    w.total = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
     return w;
 }
 }  // namespace
 
 extern "C" size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int top_k) {
     if (n_total <= 0 || HW <= 0 || top_k <= 0) return 0;
-    return ws_layout(HW).total;
+    return ws_layout(HW, n_total).total;
 }
 
 extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg, const float* qk, const float* qe, int Ck, int HW,
@@ -1096,7 +1111,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     }
     if (base < top_k) return XMEM_ERR_TOPK;
     for (int i = ns; i < XMEM_MAX_SEGMENTS; ++i) { a.seg[i].key = nullptr; a.seg[i].shr = nullptr; a.seg[i].n = 0; a.seg[i].base = base; a.seg[i].tile0 = tiles; a.seg[i].pad = 0; }
-    const WsLayout wl = ws_layout(HW);
+    const WsLayout wl = ws_layout(HW, base);
     if (!workspace || workspace_bytes < wl.total) return XMEM_ERR_WORKSPACE;
     char* ws = reinterpret_cast<char*>(workspace);
     a.n_seg = ns; a.total_tiles = tiles; a.qk = qk; a.qe = qe; a.HW = HW; a.top_k = top_k;
@@ -1165,8 +1180,22 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         h.old_seg = n_seg;
         h.hint_idx = hint->idx; h.hint_k = hint->top_k; h.grid_w = hint->grid_w > 0 ? hint->grid_w : 0;
         h.qk = qk; h.qe = qe; h.HW = HW; h.top_k = top_k; h.tau0 = tau0; h.gcnt = gcnt; h.ovf = ovf;
+        const bool use16 = aff_use_filter16();
+        h.qop16 = use16 ? reinterpret_cast<_Float16*>(ws + wl.qop16_off) : nullptr;
+        h.qmeta = use16 ? reinterpret_cast<float*>(ws + wl.qmeta_off) : nullptr;
         hipLaunchKernelGGL(affinity_hint_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), 0, s, h);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        if (use16) {
+            // fp16 filter + exact fp32 refine (affinity_filter.hip): same outputs as the fp32 select below, bit for bit
+            Filter16Args f;
+            for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) f.seg[i] = a.seg[i];
+            f.n_seg = ns; f.total_tiles = tiles; f.qk = qk; f.qe = qe; f.HW = HW; f.top_k = top_k;
+            f.splits = 0; f.tiles_per_split = 0;
+            f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
+            f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(gcand); f.gcnt = gcnt;
+            f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;
+            return aff_filter16_launch(f, stream);
+        }
     } else {
         // sampled bound pass: every 4th 32-row tile (every 8th for very large chunk-dealt memories)
         int R = 4;
@@ -1330,7 +1359,7 @@ __global__ void similarity_dense_kernel(const float* __restrict__ key, const flo
         for (int c = threadIdx.x; c < Ck; c += 64) {
             const float k = qk[(size_t)p * Ck + c];
             const float e = qe ? qe[(size_t)p * Ck + c] : 1.f;
-            blo[c] = -e; bhi[c] = 2.f * (k * e); bs += e * (k * k);
+            blo[c] = -e; bhi[c] = 2.f * (k * e); bs = bsq_term(bs, e, k);
         }
         bs = wave_sum(bs);
         if (threadIdx.x == 0) bsq_s = qe ? bs : 0.f;

@@ -1,0 +1,47 @@
+// Definitions shared by the memory-readout kernels (affinity.hip: fp32 MFMA select; affinity_filter.hip: fp16-filter + exact refine).
+#pragma once
+#include "common.hpp"
+#include <math.h>
+
+#define AFF_ROWS 32        // memory rows per wave tile
+#define AFF_MAX_TOPK 64
+#define AFW_GCAP 2048      // per-query global candidate list (all splits of the large-memory select kernels)
+
+typedef unsigned long long u64;
+
+struct SegDev { const float* key; const float* shr; int n; int base; int tile0; int pad; };
+
+// 64-bit candidate key: larger similarity first, then LOWER memory index (keys are unique because the index is part of them)
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ u64 pack_key(float v, int idx) { return ((u64)f2ord(v) << 32) | (u64)(0xffffffffu - (unsigned)idx); }
+__device__ __forceinline__ float key_val(u64 k) { return ord2f((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_idx(u64 k) { return (int)(0xffffffffu - (unsigned)k); }
+
+// one term of b_sq = sum_c e_c k_c^2 (memory_util.py:30): ONE rounding of k*k, then a fused multiply-add - spelled out so that
+// every kernel that stages a query (select kernels, filter, refine) produces the same bits whatever the contraction setting
+__device__ __forceinline__ float bsq_term(float bs, float e, float k) { return fmaf(e, k * k, bs); }
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// fp16-filter pipeline (affinity_filter.hip), launched by xmem_affinity_topk_hinted when a hint bound is available
+struct Filter16Args {
+    SegDev seg[XMEM_MAX_SEGMENTS];
+    int n_seg, total_tiles;
+    const float* qk; const float* qe;
+    int HW, top_k;
+    int splits, tiles_per_split;     // set by aff_filter16_launch
+    const _Float16* qop16;           // [HW][128] fp16 (-e | 2ke)                       } written by the bound kernel
+    const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), ||qe|| and ||2ke|| rounded up, 0   }
+    const float* tau_init;           // [HW] valid lower bound of the exact k-th similarity, or -inf (-> the query is scanned in full)
+    u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
+    int* gcand32; int* gcnt;         // [HW][AFW_GCAP] candidate indices, [HW] zeroed by the bound kernel; gcnt > AFW_GCAP: full scan
+    float* out_w; int* out_idx; float* out_sim;
+};
+size_t aff_filter16_mask_bytes(int n_total, int HW);
+int aff_filter16_launch(Filter16Args a, void* stream);
