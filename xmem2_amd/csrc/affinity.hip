@@ -810,11 +810,18 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
             for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i)
                 if (i + 1 < p.old_seg && o >= ob + p.old_n[i]) { ob += p.old_n[i]; sgi = i + 1; }
             o -= ob;
-            sgi = p.new_of_old[sgi];
+            {   // per-lane index into kernel-argument arrays: select, do not load (see seg_of_slot)
+                int mapped = p.new_of_old[0];
+#pragma unroll
+                for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+                    if (sgi == i) mapped = p.new_of_old[i];
+                sgi = mapped;
+            }
             if (sgi >= p.n_seg) sgi = p.n_seg - 1;
+            const SegDev sd = seg_of_slot(p, sgi);
             if (o < 0) o = 0;
-            if (o >= p.seg[sgi].n) o = p.seg[sgi].n - 1;
-            const int gi = p.seg[sgi].base + o;
+            if (o >= sd.n) o = sd.n - 1;
+            const int gi = sd.base + o;
             bool uniq = false;
             unsigned h = ((unsigned)gi * 2654435761u) >> 23;
             for (int probe = 0; probe < 512; ++probe) {
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
                 h = (h + 1) & 511u;
             }
             if (uniq) {
-                const float* row = p.seg[sgi].key + (size_t)o * CK;
+                const float* row = sd.key + (size_t)o * CK;
                 f32x4 xr[CK / 4];                                // the whole row in flight at once
 #pragma unroll
                 for (int c4 = 0; c4 < CK / 4; ++c4) xr[c4] = *reinterpret_cast<const f32x4*>(row + c4 * 4);
@@ -843,7 +850,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
                 }
                 const float acc = (accv[0] + accv[1]) + (accv[2] + accv[3]);
                 const float aacc = (aaccv[0] + aaccv[1]) + (aaccv[2] + aaccv[3]);
-                const float ms = p.seg[sgi].shr ? p.seg[sgi].shr[o] : 1.f;
+                const float ms = sd.shr ? sd.shr[o] : 1.f;
                 const float est = (acc - bs) * (ms * 0.125f);
                 const float margin = (aacc + fabsf(bs)) * (fabsf(ms) * 0.125f) * 3.2e-5f + 1e-30f;   // > 2 * 130 * 2^-24 * sum|terms|
                 v = est - margin;

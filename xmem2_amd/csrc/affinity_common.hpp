@@ -11,6 +11,30 @@ typedef unsigned long long u64;
 
 struct SegDev { const float* key; const float* shr; int n; int base; int tile0; int pad; };
 
+// Segment lookup with a PER-LANE index: p.seg[i] for a constant i is a scalar kernel-argument load, p.seg[lane_value] would be a
+// vector memory load from the argument buffer (one more ~1 us dependent latency) - so select field by field instead.
+template <class P> __device__ __forceinline__ SegDev seg_of_row(const P& p, int gi) {       // segment holding global row gi
+    SegDev s = p.seg[0];
+#pragma unroll
+    for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+        if (i < p.n_seg && gi >= p.seg[i].base) s = p.seg[i];
+    return s;
+}
+template <class P> __device__ __forceinline__ SegDev seg_of_tile(const P& p, int tile) {    // segment holding 32-row tile `tile`
+    SegDev s = p.seg[0];
+#pragma unroll
+    for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+        if (i < p.n_seg && tile >= p.seg[i].tile0) s = p.seg[i];
+    return s;
+}
+template <class P> __device__ __forceinline__ SegDev seg_of_slot(const P& p, int slot) {
+    SegDev s = p.seg[0];
+#pragma unroll
+    for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
+        if (slot == i) s = p.seg[i];
+    return s;
+}
+
 // 64-bit candidate key: larger similarity first, then LOWER memory index (keys are unique because the index is part of them)
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned u = __float_as_uint(f);

@@ -18,6 +18,9 @@
 //            bit-identical to the fp32 path's.  A query whose list overflows (or that has no bound) is scanned in full by
 //            its refine wave, exactly.
 #include "affinity_common.hpp"
+#ifndef SC_DBG
+#define SC_DBG 0      // timing experiments only (tools/probes/filter_ab.sh)
+#endif
 
 #define F16_BQ 128             // queries per filter workgroup (4 blocks of 32)
 #define F16_WAVES 4
@@ -191,14 +194,17 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            u64 mine = 0ull;
+            int mlo = 0, mhi = 0;                                   // lane r < 16 collects word r (v_writelane: 2 instructions per word)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // NaN-safe "upper estimate >= tau": a non-finite estimate keeps the pair for the exact pass
                 const u64 m = __ballot(!(fmaf(c[i][r], msr[r], eps[r]) < my_tau[i]));
-                if (lane == r) mine = m;
+                // gfx950: a VALU write of an SGPR needs 2 wait states before a VALU read of it; the compiler cannot see into the asm
+                asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                    : "+v"(mlo), "+v"(mhi) : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(r));
             }
-            if (lane < 16) p.mask[((blk0 + i) * (size_t)p.total_tiles + tile) * 16 + lane] = mine;
+            if (lane < 16)
+                p.mask[((blk0 + i) * (size_t)p.total_tiles + tile) * 16 + lane] = ((u64)(unsigned)mhi << 32) | (u64)(unsigned)mlo;
         }
     }
 }
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
 // ============================================================ scan =====================================================
 // bit (word r, lane j) of tile t, query block b  <->  query 32 b + (j & 31), row 32 (t - tile0) + (r & 3) + 8 (r >> 2) + 4 (j >> 5)
 #define SCAN_TILES 128
-#define SCAN_CAP 64
+#define SCAN_CAP 192
 __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     __shared__ int s_cnt[32], s_base[32];
     __shared__ int s_buf[32][SCAN_CAP];
@@ -221,18 +227,19 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         u64 m[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) m[u] = (w0 + 256 * u < nt * 16) ? words[w0 + 256 * u] : 0ull;
+#if SC_DBG == 1
+        if ((m[0] ^ m[1] ^ m[2] ^ m[3]) == 0x123456789ull) p.gcnt[0] = 1;
+        continue;
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int w = w0 + 256 * u;
             u64 mm = m[u];
             if (!mm) continue;
             const int tile = t0 + (w >> 4), r = w & 15;
-            int sg = 0;
-#pragma unroll
-            for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
-                if (i < p.n_seg && tile >= p.seg[i].tile0) sg = i;
-            const int rbase = (tile - p.seg[sg].tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2);
-            const int segn = p.seg[sg].n, gbase = p.seg[sg].base;
+            const SegDev sd = seg_of_tile(p, tile);
+            const int rbase = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2);
+            const int segn = sd.n, gbase = sd.base;
             while (mm) {
                 const int j = __ffsll((long long)mm) - 1;
                 mm &= mm - 1;
@@ -250,6 +257,9 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         }
     }
     __syncthreads();
+#if SC_DBG == 2
+    return;
+#endif
     if (tid < 32) {
         const int n = min(s_cnt[tid], SCAN_CAP), qg = b * 32 + tid;
         s_base[tid] = (n > 0 && qg < p.HW) ? atomicAdd(&p.gcnt[qg], n) : 0;
@@ -263,19 +273,19 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
 }
 
 // ============================================================ refine ===================================================
-// One WAVE per query: exact similarities of its candidates (or of ALL memory elements when the list overflowed / no bound
-// existed) 64 at a time, a running list of the best kept by counting ranks, softmax exactly as affinity_merge16_kernel
-// computes it.
-#define RF_BUF 192             // running list: compacted to the best top_k whenever another 64 might not fit
+// One workgroup (4 waves) per query: exact similarities of its candidates (or of ALL memory elements when the list overflowed
+// or no bound existed), 64 per wave and round, each wave keeping a running list of its best by counting ranks; wave 0 merges
+// the four lists and applies the softmax exactly as affinity_merge16_kernel computes it.
+#define RF_BUF 256             // running list of a wave: compacted to the best top_k whenever another 64 might not fit
 __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
     constexpr int CK = 64;
-    __shared__ __attribute__((aligned(16))) float s_op[4][2 * CK];
+    __shared__ __attribute__((aligned(16))) float s_op[2 * CK];
     __shared__ __attribute__((aligned(16))) u64 s_keys[4][RF_BUF + 2];
+    __shared__ int s_n[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wv;
-    if (q >= p.HW) return;
-    float* ne = s_op[wv]; float* ke2 = ne + CK; u64* keys = s_keys[wv];
-    {
+    const int q = blockIdx.x;
+    float* ne = s_op; float* ke2 = s_op + CK; u64* keys = s_keys[wv];
+    if (wv == 0) {
         const float k = p.qk[(size_t)q * CK + lane];
         const float e = p.qe ? p.qe[(size_t)q * CK + lane] : 1.f;
         ne[lane] = -e; ke2[lane] = 2.f * (k * e);
@@ -286,42 +296,89 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
     int total = T;
     if (full) { total = 0; for (int i = 0; i < p.n_seg; ++i) total += p.seg[i].n; }
     const int* list = p.gcand32 + (size_t)q * AFW_GCAP;
-    __builtin_amdgcn_wave_barrier();
+    int gi_next = 0;
+    if (wv * 64 + lane < total) gi_next = full ? wv * 64 + lane : list[wv * 64 + lane];
+    __syncthreads();
 
-    // exact ranks of keys[0..n) by counting; the best min(n, keepn) move to the front in order; returns the new length
+    // The best min(n, keepn) of keys[0..n) move to the front in descending order; returns the new length.  n <= RF_BUF, keepn <= 64.
+    // Selection: the keepn-th largest key by bitwise descent (value half first, the index half only among exact ties), then
+    // the survivors are ranked by counting (keys are unique).
     auto compact = [&](int n, int keepn) -> int {
-        if (lane == 0) keys[n] = 0ull;
         __builtin_amdgcn_wave_barrier();
-        u64 mine[3]; int rk[3];
+        if (n > keepn) {
+            const int per = (n + 63) >> 6;                             // uniform
+            unsigned hi[4], lo[4];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) { const int e = lane + 64 * u; mine[u] = e < n ? keys[e] : ~0ull; rk[u] = 0; }
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * u;
+                const u64 k = e < n ? keys[e] : 0ull;                  // valid keys have a non-zero value half
+                hi[u] = (unsigned)(k >> 32); lo[u] = (unsigned)k;
+            }
+            unsigned pre = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned cand = pre | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < per) c += __popcll(__ballot(hi[u] >= cand));
+                if (c >= keepn) pre = cand;
+            }
+            int cg = 0, ce = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < per) { cg += __popcll(__ballot(hi[u] > pre)); ce += __popcll(__ballot(hi[u] == pre)); }
+            const int need = keepn - cg;                                // >= 1 of the ce elements tied at the threshold value
+            unsigned lpre = 0u;
+            if (ce > need) {                                            // exact ties: the larger index half (= lower memory index) wins
+                for (int bit = 31; bit >= 0; --bit) {
+                    const unsigned cand = lpre | (1u << bit);
+                    int c = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < per) c += __popcll(__ballot(hi[u] == pre && lo[u] >= cand));
+                    if (c >= need) lpre = cand;
+                }
+            }
+            int pos = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u < per) {
+                    const bool kp = hi[u] > pre || (hi[u] == pre && lo[u] >= lpre);
+                    const unsigned long long m = __ballot(kp);
+                    if (kp) keys[pos + __popcll(m & ((1ull << lane) - 1ull))] = ((u64)hi[u] << 32) | lo[u];
+                    pos += __popcll(m);
+                }
+            }
+            n = pos;                                                    // == keepn
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) { keys[n] = 0ull; keys[n + 1] = 0ull; }
+        __builtin_amdgcn_wave_barrier();
+        const u64 mine = lane < n ? keys[lane] : ~0ull;
+        int rk = 0;
+#pragma unroll 4
         for (int f = 0; f < n; f += 2) {
             const ulonglong2 kf = *reinterpret_cast<const ulonglong2*>(keys + f);
-            const u64 k1 = f + 1 < n ? kf.y : 0ull;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) rk[u] += (int)(kf.x > mine[u]) + (int)(k1 > mine[u]);
+            rk += (int)(kf.x > mine) + (int)(kf.y > mine);             // the padding keys are 0: never greater
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < 3; ++u) { const int e = lane + 64 * u; if (e < n && rk[u] < keepn) keys[rk[u]] = mine[u]; }
+        if (lane < n) keys[rk] = mine;
         __builtin_amdgcn_wave_barrier();
-        return n < keepn ? n : keepn;
+        return n;
     };
 
     int cnt = 0;
-    float thr = -INFINITY;                            // raised to the k-th best once k candidates are known
-    for (int b0 = 0; b0 < total; b0 += 64) {
+    float thr = -INFINITY;                            // raised to the wave's k-th best once it knows k candidates
+    for (int b0 = wv * 64; b0 < total; b0 += 256) {
         const int e = b0 + lane;
-        bool pass = false; float s = 0.f; int gi = 0;
+        const int gi = gi_next;
+        if (e + 256 < total) gi_next = full ? e + 256 : list[e + 256];       // next round's index in flight under this round
+        bool pass = false; float s = 0.f;
         if (e < total) {
-            gi = full ? e : list[e];
-            int sg = 0;
-#pragma unroll
-            for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
-                if (i < p.n_seg && gi >= p.seg[i].base) sg = i;
-            const int o = gi - p.seg[sg].base;
-            const float msr = (p.seg[sg].shr ? p.seg[sg].shr[o] : 1.f) * 0.125f;
-            s = exact_sim(p.seg[sg].key + (size_t)o * CK, ne, ke2, bs, msr);
+            const SegDev sd = seg_of_row(p, gi);
+            const int o = gi - sd.base;
+            const float msr = (sd.shr ? sd.shr[o] : 1.f) * 0.125f;
+            s = exact_sim(sd.key + (size_t)o * CK, ne, ke2, bs, msr);
             pass = s >= thr;                          // NaN never enters (as in the fp32 select)
         }
         const unsigned long long m = __ballot(pass);
@@ -333,6 +390,18 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if (total > 64) {                                 // more than one wave had work: every wave hands over its best top_k
+        cnt = compact(cnt, p.top_k);
+        if (lane == 0) s_n[wv] = cnt;
+        __syncthreads();
+        if (wv != 0) return;
+        for (int w = 1; w < 4; ++w) {
+            const int nw = s_n[w];
+            if (lane < nw) keys[cnt + lane] = s_keys[w][lane];
+            cnt += nw;
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (wv != 0) return;
     cnt = compact(cnt, p.top_k);
     // softmax without max shift (memory_util.py:48-49), summed exactly as affinity_merge16_kernel: 16 lanes, r = l, l+16, ...
     if (lane < 16) {
@@ -366,6 +435,6 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     if (rc != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_scan_kernel, dim3(qt * 4, cdiv(a.total_tiles, SCAN_TILES)), dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_refine_kernel, dim3(cdiv(a.HW, 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(affinity_refine_kernel, dim3(a.HW), dim3(256), 0, s, a);
     return xmem_check_launch();
 }
