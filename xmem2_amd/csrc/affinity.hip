@@ -757,14 +757,16 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         bs = p.qe ? e * (k * k) : 0.f;
     }
     if (p.qop16) {
-        // operands of the fp16 filter, once per call: fp16 (-e | 2ke), b_sq exactly as the select kernels stage it (four parts
-        // of 16 sequential terms, then the pairwise tree), and the two operand norms (rounded up)
+        // query operand row of the fp16 filter (layout: affinity_common.hpp), once per call; b_sq exactly as the select kernels
+        // stage it (four parts of 16 sequential terms, then the pairwise tree) for the exact refine pass
         const float k = p.qk[(size_t)q * CK + lane];
         const float e = p.qe ? p.qe[(size_t)q * CK + lane] : 1.f;
         const float ke2 = 2.f * (k * e);
-        p.qop16[(size_t)q * 2 * CK + lane] = (_Float16)(-e);
-        p.qop16[(size_t)q * 2 * CK + CK + lane] = (_Float16)ke2;
+        _Float16* orow = p.qop16 + (size_t)q * F16_K;
+        orow[lane] = (_Float16)(-e);
+        orow[CK + lane] = (_Float16)ke2;
         const float sC = wave_sum(e * e), sD = wave_sum(ke2 * ke2);
+        const float mx = wave_max(fmaxf(fabsf(e), fabsf(ke2)));
         float part = 0.f;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -773,10 +775,24 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
         }
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
+        const float bsq = p.qe ? part : 0.f;
         if (lane == 0) {
-            f32x4 m;
-            m[0] = p.qe ? part : 0.f; m[1] = sqrtf(sC) * 1.0001f; m[2] = sqrtf(sD) * 1.0001f; m[3] = 0.f;
+            f32x4 m; m[0] = bsq; m[1] = 0.f; m[2] = 0.f; m[3] = 0.f;
             *reinterpret_cast<f32x4*>(p.qmeta + (size_t)q * 4) = m;
+        }
+        if (lane < 16) {
+            float C = sqrtf(sC) * 1.0001f, D = sqrtf(sD) * 1.0001f;
+            if (!(fmaxf(mx, fabsf(bsq)) < 6.5e4f)) { C = INFINITY; D = INFINITY; }   // beyond the fp16 range (or NaN): no bound, keep every pair
+            const _Float16 bh = (_Float16)bsq;
+            const _Float16 bl = (_Float16)(bsq - (float)bh);
+            _Float16 v = (_Float16)0.f;
+            if (lane == 0 || lane == 2) v = -bh;
+            else if (lane == 1) v = -bl;
+            else if (lane == 3) v = f16_up(C);
+            else if (lane == 4) v = f16_up(D);
+            else if (lane == 5) v = f16_up(F16_ACC * fabsf(bsq) + F16_ABS * (C + D));
+            else if (lane == 6) v = (_Float16)0.0009765625f;          // 2^-10
+            orow[2 * CK + lane] = v;
         }
     }
     bs = wave_sum(bs);
@@ -1067,7 +1083,7 @@ inline bool aff_use_filter16() {
     return !(e && e[0] == '0');
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, total; int fsplits; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, rows16_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
 #define AFF_FB_GRID 128     // persistent workgroups of the safe fallback pass (a scene cut flags every tile: ~0.7 ms at B32)
 inline int fallback_splits(int HW) { (void)HW; return 16; }
@@ -1085,9 +1101,10 @@ WsLayout ws_layout(int HW, int n_total) {
     // fallback buffers: one per persistent workgroup, cap = 96 + 128
     w.qop16_off = w.spill_off + align_up((size_t)AFF_FB_GRID * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64), 256);
     // fp16 filter: query operands, per-query meta, candidate bit matrix
-    w.qmeta_off = w.qop16_off + align_up((size_t)HW * 128 * sizeof(_Float16), 256);
+    w.qmeta_off = w.qop16_off + align_up((size_t)HW * F16_K * sizeof(_Float16), 256);
     w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
-    w.total = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
+    w.rows16_off = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
+    w.total = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
     return w;
 }
 }  // namespace
@@ -1199,6 +1216,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
             f.n_seg = ns; f.total_tiles = tiles; f.qk = qk; f.qe = qe; f.HW = HW; f.top_k = top_k;
             f.splits = 0; f.tiles_per_split = 0;
             f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
+            f.rows16 = reinterpret_cast<_Float16*>(ws + wl.rows16_off);
             f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(gcand); f.gcnt = gcnt;
             f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;
             return aff_filter16_launch(f, stream);

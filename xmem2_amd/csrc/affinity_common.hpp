@@ -53,6 +53,20 @@ __device__ __forceinline__ float bsq_term(float bs, float e, float k) { return f
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
+// ---- fp16 filter operands (affinity_filter.hip): K = 128 contraction terms + 16 augmentation terms -------------------------
+// row n   : [ msr x^2 (64) | msr x (64) | msr_hi, msr_hi, msr_lo, kA, kB, |msr|^, zA, 0 x 9 ]      msr = shrinkage / 8
+// query q : [   -e    (64) |  2ke  (64) | -bs_hi, -bs_lo, -bs_hi, C^, D^,  mq^, 2^-10, 0 x 9 ]
+//   kA = (KAPPA ||x^2|| |msr|)^, kB = (KAPPA ||x|| |msr|)^, C = ||e||, D = ||2ke||, mq = ACC |b_sq| + ABS (C + D),
+//   zA = (ABS (||x^2|| + ||x||) |msr| 2^10)^ or +inf when the row leaves the fp16 range;  ^ = rounded up to fp16.
+// The fp32-accumulated dot product of the two is a(n,q) + eps(n,q): an UPPER bound of the exact similarity (see the file header).
+#define F16_K 144              // halfs per operand row (288 B)
+#ifndef F16_KAPPA
+#define F16_KAPPA 1.07e-3f     // 2^-10 * 1.05 (two fp16 roundings per product) + 4.5e-5 (fp32 accumulation of filter and refine)
+#endif
+#define F16_ACC 4.5e-5f        // the same accumulation term on |b_sq| (it rides in the accumulator of both chains)
+#define F16_ABS 3e-7f          // absolute rounding error of an fp16 SUBNORMAL operand (2^-25), x sqrt(64) via Cauchy-Schwarz
+__device__ __forceinline__ _Float16 f16_up(float v) { return (_Float16)(v * 1.001f + 6e-8f); }   // >= v for v >= 0 (RNE is off by <= 2^-11 rel / 3e-8 abs)
+
 // fp16-filter pipeline (affinity_filter.hip), launched by xmem_affinity_topk_hinted when a hint bound is available
 struct Filter16Args {
     SegDev seg[XMEM_MAX_SEGMENTS];
@@ -60,12 +74,14 @@ struct Filter16Args {
     const float* qk; const float* qe;
     int HW, top_k;
     int splits, tiles_per_split;     // set by aff_filter16_launch
-    const _Float16* qop16;           // [HW][128] fp16 (-e | 2ke)                       } written by the bound kernel
-    const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), ||qe|| and ||2ke|| rounded up, 0   }
+    const _Float16* qop16;           // [HW][F16_K] query operand rows          } written by the bound kernel
+    const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), 0, 0, 0   }
+    _Float16* rows16;                // [N + 32][F16_K] memory operand rows, written by the rows kernel of the same launch
     const float* tau_init;           // [HW] valid lower bound of the exact k-th similarity, or -inf (-> the query is scanned in full)
     u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
     int* gcand32; int* gcnt;         // [HW][AFW_GCAP] candidate indices, [HW] zeroed by the bound kernel; gcnt > AFW_GCAP: full scan
     float* out_w; int* out_idx; float* out_sim;
 };
 size_t aff_filter16_mask_bytes(int n_total, int HW);
+size_t aff_filter16_rows_bytes(int n_total);
 int aff_filter16_launch(Filter16Args a, void* stream);

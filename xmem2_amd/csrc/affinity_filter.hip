@@ -18,18 +18,16 @@
 //            bit-identical to the fp32 path's.  A query whose list overflows (or that has no bound) is scanned in full by
 //            its refine wave, exactly.
 #include "affinity_common.hpp"
+#ifndef F16_DBG
+#define F16_DBG 0      // 1 prologue only, 2 no tile loads after the first, 3 loads only, 4 no mask stores
+#endif
 #ifndef SC_DBG
 #define SC_DBG 0      // timing experiments only (tools/probes/filter_ab.sh)
 #endif
 
 #define F16_BQ 128             // queries per filter workgroup (4 blocks of 32)
 #define F16_WAVES 4
-#define F16_LDB 272            // bytes per query row of the fp16 operand (256 + 16: odd multiple of 16 B)
-#ifndef F16_KAPPA
-#define F16_KAPPA 1.07e-3f     // 2^-10 * 1.05 (two fp16 roundings per product) + 4.5e-5 (fp32 accumulation of filter and refine)
-#endif
-#define F16_ACC 4.5e-5f        // the same accumulation term on |b_sq| (it rides in the accumulator of both chains)
-#define F16_ABS 3e-7f          // absolute rounding error of an fp16 SUBNORMAL operand (2^-25), x sqrt(64) via Cauchy-Schwarz
+#define F16_LDB 304            // bytes per query operand row in LDS (288 + 16: odd multiple of 16 B)
 
 // the exact similarity of ONE (row, query) pair: the fmaf chain of the fp32 MFMA select (affinity_wide_kernel):
 // accumulator starts at -b_sq; per 8-channel group t and j = 0..3: k-pairs (8t+j, 8t+4+j) of [x^2 * -e] then of [x * 2ke].
@@ -54,151 +52,149 @@ __device__ __forceinline__ float exact_sim(const float* __restrict__ row, const 
     return acc * msr;
 }
 
+// ============================================================ rows ======================================================
+// fp16 operand rows of the memory (layout: affinity_common.hpp), 16 lanes per row.  Depends on (key, shrinkage) only.
+__global__ __launch_bounds__(256) void affinity_rows16_kernel(Filter16Args p, int n_total) {
+    constexpr int CK = 64;
+    const int l = threadIdx.x & 15;
+    const int gi = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (gi >= n_total) return;
+    const SegDev sd = seg_of_row(p, gi);
+    const int o = gi - sd.base;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(sd.key + (size_t)o * CK + 4 * l);
+    const float msr = (sd.shr ? sd.shr[o] : 1.f) * 0.125f;
+    float sA = 0.f, sB = 0.f, mx = fabsf(msr);
+    typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+    h16x4 h2, h1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float q = x[j] * x[j];
+        const float a2 = msr * q, a1 = msr * x[j];
+        sA += q * q; sB += q;
+        mx = fmaxf(mx, fmaxf(fabsf(a2), fabsf(a1)));
+        h2[j] = (_Float16)a2; h1[j] = (_Float16)a1;
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) {
+        sA += __shfl_xor(sA, d, 16); sB += __shfl_xor(sB, d, 16); mx = fmaxf(mx, __shfl_xor(mx, d, 16));
+    }
+    _Float16* orow = p.rows16 + (size_t)gi * F16_K;
+    *reinterpret_cast<h16x4*>(orow + 4 * l) = h2;
+    *reinterpret_cast<h16x4*>(orow + CK + 4 * l) = h1;
+    const float An = sqrtf(sA) * 1.0001f, Bn = sqrtf(sB) * 1.0001f, am = fabsf(msr);
+    const _Float16 mh = (_Float16)msr;
+    _Float16 v = (_Float16)0.f;
+    if (l == 0 || l == 1) v = mh;
+    else if (l == 2) v = (_Float16)(msr - (float)mh);
+    else if (l == 3) v = f16_up(F16_KAPPA * An * am);
+    else if (l == 4) v = f16_up(F16_KAPPA * Bn * am);
+    else if (l == 5) v = f16_up(am);
+    else if (l == 6) {
+        // every operand of the row must be inside the fp16 range (NaN fails the test too); otherwise no bound: keep every pair
+        const float z = F16_ABS * (An + Bn) * am * 1024.f;
+        v = (mx < 6.5e4f && z < 6.5e4f) ? f16_up(z) : (_Float16)INFINITY;
+    }
+    orow[2 * CK + l] = v;
+}
+
 // ============================================================ filter ===================================================
 // grid (query tiles of 128, splits of the memory), 4 waves; wave w of split s takes tiles t_begin + w, + 4, ...
-// Per 32-row tile and 32-query block: 8 x v_mfma_f32_32x32x16_f16, then 16 compares whose lane masks ARE the output words.
+// Per 32-row tile and 32-query block: 9 x v_mfma_f32_32x32x16_f16 give the UPPER estimates directly (augmented operands),
+// then 16 compares against tau whose lane masks ARE the output words.
 __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args p) {
-    constexpr int CK = 64;
-    __shared__ __attribute__((aligned(16))) unsigned char Bh[F16_BQ * F16_LDB];   // fp16 (-e | 2ke) per query
-    __shared__ float s_bs[F16_BQ], s_tau[F16_BQ];
-    __shared__ unsigned s_qmax[3];                                                  // max ||qe||, ||2ke||, |b_sq| (bits of non-negative floats)
-    __shared__ __attribute__((aligned(16))) float s_row[F16_WAVES][AFF_ROWS][2];    // per wave: (ms / 8, eps) of the tile's rows
-
+    __shared__ __attribute__((aligned(16))) unsigned char Bh[F16_BQ * F16_LDB];
+    __shared__ float s_tau[F16_BQ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int q0 = blockIdx.x * F16_BQ;
     const int split = blockIdx.y;
 
-    if (tid < 3) s_qmax[tid] = 0u;
-    __syncthreads();
-    // query operand: 128 rows of 256 B prepared once per call by the bound kernel (coalesced 16-B copies)
-    for (int e = tid; e < F16_BQ * 16; e += 256) {
-        const int q = e >> 4, part = e & 15, qg = q0 + q;
+    // query operands: 128 rows of 288 B prepared once per call by the bound kernel (coalesced 16-B copies)
+    for (int e = tid; e < F16_BQ * 18; e += 256) {
+        const int q = e / 18, part = e - q * 18, qg = q0 + q;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (qg < p.HW) v = *reinterpret_cast<const uint4*>(p.qop16 + (size_t)qg * 2 * CK + part * 8);
+        if (qg < p.HW) v = *reinterpret_cast<const uint4*>(p.qop16 + (size_t)qg * F16_K + part * 8);
         *reinterpret_cast<uint4*>(Bh + q * F16_LDB + part * 16) = v;
     }
     if (tid < F16_BQ) {
         const int qg = q0 + tid;
-        float t0 = INFINITY, bs = 0.f;
+        float t0 = INFINITY;
         if (qg < p.HW) {
-            const f32x4 m = *reinterpret_cast<const f32x4*>(p.qmeta + (size_t)qg * 4);
-            bs = m[0];
-            atomicMax(&s_qmax[0], __float_as_uint(m[1]));
-            atomicMax(&s_qmax[1], __float_as_uint(m[2]));
-            atomicMax(&s_qmax[2], __float_as_uint(fabsf(bs)));
             t0 = p.tau_init[qg];
             if (t0 == -INFINITY) {                                   // no bound: the refine scans this query in full
                 if (split == 0) p.gcnt[qg] = AFW_GCAP + 1;
                 t0 = INFINITY;
             }
         }
-        s_bs[tid] = bs; s_tau[tid] = t0;
+        s_tau[tid] = t0;
     }
     __syncthreads();
-    float Cmax = __uint_as_float(s_qmax[0]), Dmax = __uint_as_float(s_qmax[1]);
-    const float bsmax = __uint_as_float(s_qmax[2]);
-    // an operand beyond the fp16 range (|v| <= ||v||) voids the bound: eps = inf keeps every pair for the exact pass
-    if (!(Cmax < 6.5e4f)) Cmax = INFINITY;
-    if (!(Dmax < 6.5e4f)) Dmax = INFINITY;
 
+#if F16_DBG == 1
+    return;
+#endif
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
 
-    // next tile's key rows (lane: row l31, channels [16t + 8 lh, +8) for t = 0..3), row index clamped into the segment
+    // a tile's operand rows (lane: row l31, halfs [16t + 8 lh, +8) for t = 0..8), row index clamped into the segment
     // (the duplicated rows of a segment's last tile set spurious bits; the scan drops rows past the segment's end)
-    f32x4 an[8]; float msn = 1.f;
-    auto issue_loads = [&](int tile) {
+    auto issue_loads = [&](int tile, h16x8 (&dst)[9]) {
         if (tile >= t_end) return;
         int sg = 0;
 #pragma unroll
         for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
             if (i < p.n_seg && tile >= p.seg[i].tile0) sg = i;
-        const int r = min((tile - p.seg[sg].tile0) * AFF_ROWS + l31, p.seg[sg].n - 1);
-        const float* src = p.seg[sg].key + (size_t)r * CK + lh * 8;
+        const int r = p.seg[sg].base + min((tile - p.seg[sg].tile0) * AFF_ROWS + l31, p.seg[sg].n - 1);
+        const _Float16* src = p.rows16 + (size_t)r * F16_K + lh * 8;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            an[2 * t] = *reinterpret_cast<const f32x4*>(src + 16 * t);
-            an[2 * t + 1] = *reinterpret_cast<const f32x4*>(src + 16 * t + 4);
-        }
-        msn = p.seg[sg].shr ? p.seg[sg].shr[r] : 1.f;
+        for (int t = 0; t < 9; ++t) dst[t] = *reinterpret_cast<const h16x8*>(src + 16 * t);
     };
 
-    float my_tau[4], my_bs[4];
+    float my_tau[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { my_bs[i] = s_bs[i * 32 + l31]; my_tau[i] = s_tau[i * 32 + l31]; }
-    const unsigned char* bq = Bh + l31 * F16_LDB + lh * 16;
-    float* rowinfo = &s_row[wave][0][0];
+    for (int i = 0; i < 4; ++i) my_tau[i] = s_tau[i * 32 + l31];
     const size_t blk0 = (size_t)blockIdx.x * 4;
 
-    issue_loads(t_begin + wave);
-    for (int tile = t_begin + wave; tile < t_end; tile += F16_WAVES) {
-        // fp16 operands of this tile's rows: x (k >= 64) and x^2 (k < 64); row norms for eps
-        h16x8 xh[4], x2h[4];
-        float sA = 0.f, sB = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xa = an[2 * t][j], xb = an[2 * t + 1][j];
-                const float qa = xa * xa, qb = xb * xb;
-                xh[t][j] = (_Float16)xa; xh[t][4 + j] = (_Float16)xb;
-                x2h[t][j] = (_Float16)qa; x2h[t][4 + j] = (_Float16)qb;
-                sB += qa + qb; sA += qa * qa + qb * qb;
-            }
-        }
-        const float msr_mine = msn * 0.125f;
-        issue_loads(tile + F16_WAVES);                          // next tile's rows in flight under this tile's work
-        sA += __shfl_xor(sA, 32, 64); sB += __shfl_xor(sB, 32, 64);
-        // |a - S| <= eps for every query of this workgroup (header)
-        const float An = sqrtf(sA), Bn = sqrtf(sB);
-        float eps_mine = ((An * Cmax + Bn * Dmax) * F16_KAPPA + F16_ABS * (An + Bn + Cmax + Dmax) + F16_ACC * bsmax)
-                         * fabsf(msr_mine) * 1.0001f;
-        // x^2 <= sqrt(sum x^4) must stay inside the fp16 range (then |x| does too); NaN / inf rows and a NaN bound land here as well
-        if (!(sA < 4.0e9f) || !(eps_mine < INFINITY)) eps_mine = INFINITY;
-        if (lh == 0) { rowinfo[2 * l31] = msr_mine; rowinfo[2 * l31 + 1] = eps_mine; }
-
+    // one tile: 36 MFMAs in k-step order (four independent accumulator chains), the query fragments of step t + 1 requested
+    // from LDS before the MFMAs of step t; then the compares.  The LDS offset is made opaque per tile: the fragments are loop
+    // invariant and the compiler would otherwise keep all 144 registers of them resident (and spill).
+    auto do_tile = [&](int tile, const h16x8 (&a)[9]) {
+        int boff = l31 * F16_LDB + lh * 16;
+        asm volatile("" : "+v"(boff));
+        const unsigned char* bq = Bh + boff;
         f32x16 c[4];
+        h16x8 bc[4], bn[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float nb = -my_bs[i];
-            asm volatile("" : "+v"(nb));
+        for (int i = 0; i < 4; ++i) bc[i] = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[i][r] = nb;
-        }
+        for (int t = 0; t < 9; ++t) {
+            if (t < 8) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+                for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB + (t + 1) * 32);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const h16x8 blo = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB + t * 32);
-                c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2h[t], blo, c[i], 0, 0, 0);
+                if (t == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bc[i], z, 0, 0, 0);
+                } else {
+                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bc[i], c[i], 0, 0, 0);
+                }
             }
-        }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const h16x8 bhi = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB + 128 + t * 32);
-                c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[t], bhi, c[i], 0, 0, 0);
-            }
-        }
-        // (ms / 8, eps) of accumulator register r's row: rows 8g + 4 lh + {0..3} for g = r >> 2 (same-wave LDS ops are in order)
-        float msr[16], eps[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(rowinfo + 2 * (8 * g + 4 * lh));
-            const f32x4 u1 = *reinterpret_cast<const f32x4*>(rowinfo + 2 * (8 * g + 4 * lh) + 4);
-            msr[4 * g] = u0[0]; eps[4 * g] = u0[1]; msr[4 * g + 1] = u0[2]; eps[4 * g + 1] = u0[3];
-            msr[4 * g + 2] = u1[0]; eps[4 * g + 2] = u1[1]; msr[4 * g + 3] = u1[2]; eps[4 * g + 3] = u1[3];
+            for (int i = 0; i < 4; ++i) bc[i] = bn[i];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int mlo = 0, mhi = 0;                                   // lane r < 16 collects word r (v_writelane: 2 instructions per word)
+            int mlo = 0, mhi = 0;                                   // lane r < 16 collects word r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // NaN-safe "upper estimate >= tau": a non-finite estimate keeps the pair for the exact pass
-                const u64 m = __ballot(!(fmaf(c[i][r], msr[r], eps[r]) < my_tau[i]));
+                const u64 m = __ballot(!(c[i][r] < my_tau[i]));
                 // gfx950: a VALU write of an SGPR needs 2 wait states before a VALU read of it; the compiler cannot see into the asm
                 asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
                     : "+v"(mlo), "+v"(mhi) : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(r));
@@ -206,6 +202,21 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
             if (lane < 16)
                 p.mask[((blk0 + i) * (size_t)p.total_tiles + tile) * 16 + lane] = ((u64)(unsigned)mhi << 32) | (u64)(unsigned)mlo;
         }
+    };
+
+    // two tiles of operand rows in flight per wave
+    h16x8 a0[9], a1[9];
+    int tile = t_begin + wave;
+    issue_loads(tile, a0);
+    issue_loads(tile + F16_WAVES, a1);
+    while (tile < t_end) {
+        do_tile(tile, a0);
+        issue_loads(tile + 2 * F16_WAVES, a0);
+        tile += F16_WAVES;
+        if (tile >= t_end) break;
+        do_tile(tile, a1);
+        issue_loads(tile + 2 * F16_WAVES, a1);
+        tile += F16_WAVES;
     }
 }
 
@@ -223,36 +234,47 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     if (tid < 32) s_cnt[tid] = 0;
     __syncthreads();
     const u64* words = p.mask + ((size_t)b * p.total_tiles + t0) * 16;
-    for (int w0 = tid; w0 < nt * 16; w0 += 4 * 256) {
+    const int lane = tid & 63;
+    auto insert = [&](int w, int j) {                            // bit j of word w (relative to this slice)
+        const int tile = t0 + (w >> 4), r = w & 15;
+        const SegDev sd = seg_of_tile(p, tile);
+        const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (j >> 5);
+        if (row >= sd.n) return;                                 // clamped duplicate of the segment's last row
+        const int qi = j & 31, gi = sd.base + row;
+        const int slot = atomicAdd(&s_cnt[qi], 1);
+        if (slot < SCAN_CAP) s_buf[qi][slot] = gi;
+        else {                                                   // local buffer full: straight to the query's global list
+            const int qg = b * 32 + qi;
+            const int gs = atomicAdd(&p.gcnt[qg], 1);
+            if (gs < AFW_GCAP) p.gcand32[(size_t)qg * AFW_GCAP + gs] = gi;
+        }
+    };
+    for (int w0 = tid; w0 - lane < nt * 16; w0 += 4 * 256) {     // wave-uniform trip count
         u64 m[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) m[u] = (w0 + 256 * u < nt * 16) ? words[w0 + 256 * u] : 0ull;
-#if SC_DBG == 1
-        if ((m[0] ^ m[1] ^ m[2] ^ m[3]) == 0x123456789ull) p.gcnt[0] = 1;
-        continue;
-#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int w = w0 + 256 * u;
             u64 mm = m[u];
-            if (!mm) continue;
-            const int tile = t0 + (w >> 4), r = w & 15;
-            const SegDev sd = seg_of_tile(p, tile);
-            const int rbase = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2);
-            const int segn = sd.n, gbase = sd.base;
-            while (mm) {
-                const int j = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                const int row = rbase + 4 * (j >> 5);
-                if (row >= segn) continue;                       // clamped duplicate of the segment's last row
-                const int qi = j & 31, gi = gbase + row;
-                const int slot = atomicAdd(&s_cnt[qi], 1);
-                if (slot < SCAN_CAP) s_buf[qi][slot] = gi;
-                else {                                           // local buffer full: straight to the query's global list
-                    const int qg = b * 32 + qi;
-                    const int gs = atomicAdd(&p.gcnt[qg], 1);
-                    if (gs < AFW_GCAP) p.gcand32[(size_t)qg * AFW_GCAP + gs] = gi;
+            // neighbouring queries and neighbouring rows share their good matches: set bits cluster.  A lane walks a sparse
+            // word itself; a dense word is taken apart by the whole wave, one bit per lane.
+            const bool dense = __popcll(mm) > 2;
+            unsigned long long dm = __ballot(dense);
+            if (!dense) {
+                while (mm) {
+                    const int j = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    insert(w, j);
                 }
+            }
+            while (dm) {
+                const int src = __ffsll((long long)dm) - 1;
+                dm &= dm - 1;
+                const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)mm, src);
+                const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(mm >> 32), src);
+                const u64 wm = ((u64)hi << 32) | lo;
+                if ((wm >> lane) & 1ull) insert(w - lane + src, lane);
             }
         }
     }
@@ -296,8 +318,10 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
     int total = T;
     if (full) { total = 0; for (int i = 0; i < p.n_seg; ++i) total += p.seg[i].n; }
     const int* list = p.gcand32 + (size_t)q * AFW_GCAP;
-    int gi_next = 0;
-    if (wv * 64 + lane < total) gi_next = full ? wv * 64 + lane : list[wv * 64 + lane];
+    // the first round's indices are requested without waiting for the count (the list is AFW_GCAP long; stale entries are
+    // never used: every use is guarded by e < total)
+    int gi_next = list[wv * 64 + lane];
+    if (full) gi_next = wv * 64 + lane;
     __syncthreads();
 
     // The best min(n, keepn) of keys[0..n) move to the front in descending order; returns the new length.  n <= RF_BUF, keepn <= 64.
@@ -417,6 +441,8 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
     }
 }
 
+size_t aff_filter16_rows_bytes(int n_total) { return ((size_t)n_total + AFF_ROWS) * F16_K * sizeof(_Float16); }
+
 size_t aff_filter16_mask_bytes(int n_total, int HW) {
     const size_t tiles = (size_t)cdiv(n_total, AFF_ROWS) + XMEM_MAX_SEGMENTS;
     return (size_t)cdiv(HW, F16_BQ) * 4 * tiles * 16 * sizeof(u64);
@@ -430,8 +456,13 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     { int maxs = a.total_tiles / (4 * F16_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
     a.tiles_per_split = cdiv(a.total_tiles, sp);
     a.splits = cdiv(a.total_tiles, a.tiles_per_split);
-    hipLaunchKernelGGL(affinity_filter16_kernel, dim3(qt, a.splits), dim3(256), 0, s, a);
+    int n_total = 0;
+    for (int i = 0; i < a.n_seg; ++i) n_total += a.seg[i].n;
+    hipLaunchKernelGGL(affinity_rows16_kernel, dim3(cdiv(n_total, 16)), dim3(256), 0, s, a, n_total);
     int rc = xmem_check_launch();
+    if (rc != XMEM_OK) return rc;
+    hipLaunchKernelGGL(affinity_filter16_kernel, dim3(qt, a.splits), dim3(256), 0, s, a);
+    rc = xmem_check_launch();
     if (rc != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_scan_kernel, dim3(qt * 4, cdiv(a.total_tiles, SCAN_TILES)), dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
