@@ -147,6 +147,8 @@ def run_gpu(args, device, rank, world):
     from xmem2_amd.run_on_video import AsyncMaskFetcher
     from xmem2_amd.synth import synthetic_state_dict
     wl = WORKLOADS[args.workload]
+    if os.environ.get('XMEM_BENCH_MAIN_PRIORITY'):     # experiment: the frame loop on a high-priority stream (side stream stays at 0)
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ['XMEM_BENCH_MAIN_PRIORITY'])))
     cfg = workload_config(wl)
     sd = synthetic_state_dict(0)
     net = XMem(dict(cfg, precision=args.precision), None).to(device).eval()
@@ -176,11 +178,32 @@ def run_gpu(args, device, rank, world):
         if not args.no_prefetch:
             core.prefetch_keys([frame(first + j) for j in range(KB)])
 
+    host_t = {'step': 0.0, 'hint': 0.0, 'fetch': 0.0, 'n': 0} if os.environ.get('XMEM_BENCH_HOST_TIMES') else None
+
     def one_step(i):
+        if host_t is None:
+            prob = core.step(frame(i), None, None)
+            if os.environ.get('XMEM_BENCH_HINT_LATE'):
+                out = [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
+                if i % KB == 0:
+                    hint(i + KB)
+                return out
+            if i % KB == 0:                          # first frame of its batch consumed: hint the next batch under it
+                hint(i + KB)
+            return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
+        t0 = time.perf_counter()
         prob = core.step(frame(i), None, None)
-        if i % KB == 0:                              # first frame of its batch consumed: hint the next batch under it
+        t1 = time.perf_counter()
+        if i % KB == 0:
             hint(i + KB)
-        return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
+        t2 = time.perf_counter()
+        am = ops.argmax_u8(prob)
+        t2b = time.perf_counter()
+        out = [m for _, m in fetcher.submit(i, am)]
+        t3 = time.perf_counter()
+        host_t['step'] += t1 - t0; host_t['hint'] += t2 - t1; host_t['fetch'] += t3 - t2; host_t['n'] += 1
+        host_t.setdefault('by_phase', {}).setdefault(i % KB, []).append((t1 - t0, t2 - t1, t2b - t2, t3 - t2b))
+        return out
 
     # setup (untimed, like the preload): enough frames to capture every HIP graph variant the stream will replay
     # (two key batches; for dynamic memories two memory frames -> value-encoder graphs, deep-update variants)
@@ -206,6 +229,14 @@ def run_gpu(args, device, rank, world):
         ops.trace_marker(2)
     torch.cuda.synchronize(device); barrier(device)
     elapsed = time.perf_counter() - t0
+    if host_t is not None:
+        n = max(host_t['n'], 1)
+        print(f"[host ms per frame over {n} calls incl. setup] step {1e3 * host_t['step'] / n:.3f}  hint {1e3 * host_t['hint'] / n:.3f} "
+              f"(per batch {1e3 * host_t['hint'] / n * KB:.3f})  argmax+fetch {1e3 * host_t['fetch'] / n:.3f}", file=sys.stderr)
+        for ph, v in sorted(host_t.get('by_phase', {}).items()):
+            v = v[len(v) // 2:]                       # steady state
+            med = [sorted(x[j] for x in v)[len(v) // 2] * 1e3 for j in range(4)]
+            print(f"   frame i%KB={ph}: median host ms  step {med[0]:.3f}  hint {med[1]:.3f}  argmax launch {med[2]:.3f}  submit/wait {med[3]:.3f}", file=sys.stderr)
     m = core.memory
     n_elems = m.temporary_work_mem.size + m.permanent_work_mem.size + m.long_mem.size
     # ---- instrumented pass (rank 0): the SAME schedule again (graphs, two streams, batched hints) with HIP events on

@@ -482,6 +482,7 @@ struct WideArgs {
     const float* tau_init;           // [HW] valid lower bound of the k-th similarity (-inf: no bound -> tile goes to the safe kernel)
     u64* gcand; int* gcnt;           // [HW][AFW_GCAP], [HW] (zeroed by the bound kernels)
     int* ovf;                        // [ceil(HW/64)]
+    const int* only;                 // optional [ceil(HW/128)]: workgroups of query tiles whose flag is 0 return at once
 };
 
 __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
+    if (p.only && p.only[blockIdx.x] == 0) return;    // fp16-filter launches: only the query tiles whose candidate lists overflowed
     const int q0 = blockIdx.x * AFW_BQ;
     const int split = blockIdx.y;
     const int keep = p.top_k > 32 ? p.top_k : 32;     // entries a list is cut back to (>= top_k)
@@ -736,6 +738,7 @@ struct HintArgs {
     const float* qk; const float* qe; int HW, top_k;
     float* tau0; int* gcnt; int* ovf;
     _Float16* qop16; float* qmeta;       // optional: query operands of the fp16 filter (affinity_filter.hip)
+    int* gcnt2; int* flag128;            // optional: second list counters / per-128-query-tile fallback flags, zeroed here
 };
 #define HINT_MAXC 320       // 5 queries x 64 indices
 #define HINT_NB 12          // entries taken from each grid neighbour's list
@@ -798,7 +801,10 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
     bs = wave_sum(bs);
 #pragma unroll
     for (int i = 0; i < 8; ++i) tab[lane + 64 * i] = -1;
-    if (lane == 0) { p.gcnt[q] = 0; if ((q & 63) == 0) p.ovf[q >> 6] = 0; }
+    if (lane == 0) {
+        p.gcnt[q] = 0; if ((q & 63) == 0) p.ovf[q >> 6] = 0;
+        if (p.gcnt2) { p.gcnt2[q] = 0; if ((q & 127) == 0) p.flag128[q >> 7] = 0; }
+    }
     // candidate lists: this query and its grid neighbours in the hint
     int nq[5]; int nn = 0;
     nq[nn++] = q;
@@ -910,7 +916,8 @@ __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __rest
                                                                const int* __restrict__ ovf, const u64* __restrict__ part_key,
                                                                const int* __restrict__ part_cnt, int fsplits, int HW, int top_k,
                                                                int heavy_cap, float* __restrict__ out_w, int* __restrict__ out_idx,
-                                                               float* __restrict__ out_sim) {
+                                                               float* __restrict__ out_sim, const int* __restrict__ only) {
+    if (only && only[(blockIdx.x * 16) >> 7] == 0) return;     // fp16-filter launches: flagged 128-query tiles only
     __shared__ __attribute__((aligned(16))) u64 s_keys[16][AFM_LIGHT + 2];
     extern __shared__ __attribute__((aligned(16))) u64 s_heavy_dyn[];        // [4][heavy_cap + 2]: the longest list a query can have
     __shared__ float s_v[16][AFF_MAX_TOPK];
@@ -1083,7 +1090,7 @@ inline bool aff_use_filter16() {
     return !(e && e[0] == '0');
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, rows16_off, total; int fsplits; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, rows16_off, gcand32_off, gcnt2_off, flag_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
 #define AFF_FB_GRID 128     // persistent workgroups of the safe fallback pass (a scene cut flags every tile: ~0.7 ms at B32)
 inline int fallback_splits(int HW) { (void)HW; return 16; }
@@ -1104,7 +1111,10 @@ WsLayout ws_layout(int HW, int n_total) {
     w.qmeta_off = w.qop16_off + align_up((size_t)HW * F16_K * sizeof(_Float16), 256);
     w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
     w.rows16_off = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
-    w.total = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
+    w.gcand32_off = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
+    w.gcnt2_off = w.gcand32_off + align_up((size_t)HW * AFW_GCAP * sizeof(int), 256);
+    w.flag_off = w.gcnt2_off + align_up((size_t)HW * sizeof(int), 256);
+    w.total = w.flag_off + align_up((size_t)cdiv(HW, AFW_BQ) * sizeof(int), 256);
     return w;
 }
 }  // namespace
@@ -1173,7 +1183,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     WideArgs w;
     for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) w.seg[i] = a.seg[i];
     w.n_seg = ns; w.total_tiles = tiles; w.qk = qk; w.qe = qe; w.HW = HW; w.top_k = top_k;
-    w.tau_init = tau0; w.gcand = gcand; w.gcnt = gcnt; w.ovf = ovf;
+    w.tau_init = tau0; w.gcand = gcand; w.gcnt = gcnt; w.ovf = ovf; w.only = nullptr;
     // one 8-wave workgroup per CU: splits so that query tiles x splits fills (at most) the 256 CUs, >= 8 tiles per wave
     int sp = 256 / qt128; if (sp < 1) sp = 1;
     { int maxs = tiles / (8 * AFW_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
@@ -1207,19 +1217,36 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         const bool use16 = aff_use_filter16();
         h.qop16 = use16 ? reinterpret_cast<_Float16*>(ws + wl.qop16_off) : nullptr;
         h.qmeta = use16 ? reinterpret_cast<float*>(ws + wl.qmeta_off) : nullptr;
+        h.gcnt2 = use16 ? reinterpret_cast<int*>(ws + wl.gcnt2_off) : nullptr;
+        h.flag128 = use16 ? reinterpret_cast<int*>(ws + wl.flag_off) : nullptr;
         hipLaunchKernelGGL(affinity_hint_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), 0, s, h);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         if (use16) {
-            // fp16 filter + exact fp32 refine (affinity_filter.hip): same outputs as the fp32 select below, bit for bit
+            // fp16 filter + exact fp32 refine (affinity_filter.hip): same outputs as the fp32 select below, bit for bit.
+            // Query tiles whose candidate lists overflow (no usable bound: scene cut, garbage hint) are flagged by the scan and
+            // taken by the fp32 select (self-tightening lists, bound = the hint's) + merge; those two launches return at once
+            // for every other tile, the refine skips the flagged ones.
             Filter16Args f;
             for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) f.seg[i] = a.seg[i];
             f.n_seg = ns; f.total_tiles = tiles; f.qk = qk; f.qe = qe; f.HW = HW; f.top_k = top_k;
             f.splits = 0; f.tiles_per_split = 0;
             f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
             f.rows16 = reinterpret_cast<_Float16*>(ws + wl.rows16_off);
-            f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(gcand); f.gcnt = gcnt;
+            f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.flag128 = h.flag128;
             f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;
-            return aff_filter16_launch(f, stream);
+            if ((rc = aff_filter16_launch(f, 0, stream)) != XMEM_OK) return rc;             // rows, filter, scan
+            w.gcnt = h.gcnt2; w.only = h.flag128;
+            const size_t lds = ((size_t)AFW_BQ * AFF_LDB + 3 * AFW_BQ + 4) * sizeof(float) + (size_t)AFW_BQ * AFW_CAP * sizeof(u64);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
+            hipLaunchKernelGGL(affinity_wide_kernel, dim3(qt128, w.splits), dim3(512), lds, s, w);
+            if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+            int hc = w.splits * (top_k > 32 ? top_k : 32);
+            if (hc > AFW_GCAP) hc = AFW_GCAP;
+            hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), (size_t)4 * (hc + 2) * sizeof(u64), s, gcand, h.gcnt2,
+                               ovf, a.part_key, a.part_cnt, 0, HW, top_k, hc, out_w, out_idx, out_sim, (const int*)h.flag128);
+            if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+            return aff_filter16_launch(f, 1, stream);                                       // refine
         }
     } else {
         // sampled bound pass: every 4th 32-row tile (every 8th for very large chunk-dealt memories)
@@ -1246,7 +1273,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     int heavy_cap = w.splits * (top_k > 32 ? top_k : 32);          // every workgroup hands over at most max(top_k, 32) entries
     if (heavy_cap > AFW_GCAP) heavy_cap = AFW_GCAP;
     hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), (size_t)4 * (heavy_cap + 2) * sizeof(u64), s, gcand, gcnt,
-                       ovf, a.part_key, a.part_cnt, 0, HW, top_k, heavy_cap, out_w, out_idx, out_sim);
+                       ovf, a.part_key, a.part_cnt, 0, HW, top_k, heavy_cap, out_w, out_idx, out_sim, (const int*)nullptr);
     return xmem_check_launch();
 }
 

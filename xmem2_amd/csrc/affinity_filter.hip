@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
         float t0 = INFINITY;
         if (qg < p.HW) {
             t0 = p.tau_init[qg];
-            if (t0 == -INFINITY) {                                   // no bound: the refine scans this query in full
-                if (split == 0) p.gcnt[qg] = AFW_GCAP + 1;
+            if (t0 == -INFINITY) {                                   // no bound: the tile goes to the fp32 select
+                if (split == 0) p.flag128[qg >> 7] = 1;
                 t0 = INFINITY;
             }
         }
@@ -165,6 +165,13 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
         const unsigned char* bq = Bh + boff;
         f32x16 c[4];
         h16x8 bc[4], bn[4];
+#if F16_DBG == 3
+        { float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc += (float)a[t][0];
+          if (acc == 123.456f) p.gcnt[0] = 1; }
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) bc[i] = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB);
 #pragma unroll
@@ -188,6 +195,13 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
 #pragma unroll
             for (int i = 0; i < 4; ++i) bc[i] = bn[i];
         }
+#if F16_DBG == 5
+        { float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc += c[i][0] + c[i][5] + c[i][10] + c[i][15];
+          if (acc == 123.456f) p.gcnt[0] = 1; }
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int mlo = 0, mhi = 0;                                   // lane r < 16 collects word r
@@ -241,12 +255,14 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (j >> 5);
         if (row >= sd.n) return;                                 // clamped duplicate of the segment's last row
         const int qi = j & 31, gi = sd.base + row;
+        if (b * 32 + qi >= p.HW) return;                        // padding query of the last tile (only non-finite estimates reach here)
         const int slot = atomicAdd(&s_cnt[qi], 1);
         if (slot < SCAN_CAP) s_buf[qi][slot] = gi;
         else {                                                   // local buffer full: straight to the query's global list
             const int qg = b * 32 + qi;
             const int gs = atomicAdd(&p.gcnt[qg], 1);
             if (gs < AFW_GCAP) p.gcand32[(size_t)qg * AFW_GCAP + gs] = gi;
+            else if (qg < p.HW) p.flag128[qg >> 7] = 1;
         }
     };
     for (int w0 = tid; w0 - lane < nt * 16; w0 += 4 * 256) {     // wave-uniform trip count
@@ -285,6 +301,7 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     if (tid < 32) {
         const int n = min(s_cnt[tid], SCAN_CAP), qg = b * 32 + tid;
         s_base[tid] = (n > 0 && qg < p.HW) ? atomicAdd(&p.gcnt[qg], n) : 0;
+        if (qg < p.HW && s_base[tid] + n > AFW_GCAP) p.flag128[qg >> 7] = 1;    // list overflow: the tile goes to the fp32 select
     }
     __syncthreads();
     for (int e = tid; e < 32 * SCAN_CAP; e += 256) {
@@ -306,6 +323,7 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
     __shared__ int s_n[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x;
+    if (p.flag128[q >> 7]) return;                    // computed by the fp32 select + merge of this launch
     float* ne = s_op; float* ke2 = s_op + CK; u64* keys = s_keys[wv];
     if (wv == 0) {
         const float k = p.qk[(size_t)q * CK + lane];
@@ -313,15 +331,11 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
         ne[lane] = -e; ke2[lane] = 2.f * (k * e);
     }
     const float bs = p.qmeta[(size_t)q * 4];          // b_sq with the select kernels' arithmetic (bound kernel)
-    const int T = p.gcnt[q];
-    const bool full = T > AFW_GCAP;
-    int total = T;
-    if (full) { total = 0; for (int i = 0; i < p.n_seg; ++i) total += p.seg[i].n; }
+    const int total = min(p.gcnt[q], AFW_GCAP);       // (a longer list flags the tile)
     const int* list = p.gcand32 + (size_t)q * AFW_GCAP;
     // the first round's indices are requested without waiting for the count (the list is AFW_GCAP long; stale entries are
     // never used: every use is guarded by e < total)
     int gi_next = list[wv * 64 + lane];
-    if (full) gi_next = wv * 64 + lane;
     __syncthreads();
 
     // The best min(n, keepn) of keys[0..n) move to the front in descending order; returns the new length.  n <= RF_BUF, keepn <= 64.
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
     for (int b0 = wv * 64; b0 < total; b0 += 256) {
         const int e = b0 + lane;
         const int gi = gi_next;
-        if (e + 256 < total) gi_next = full ? e + 256 : list[e + 256];       // next round's index in flight under this round
+        if (e + 256 < total) gi_next = list[e + 256];       // next round's index in flight under this round
         bool pass = false; float s = 0.f;
         if (e < total) {
             const SegDev sd = seg_of_row(p, gi);
@@ -448,8 +462,12 @@ size_t aff_filter16_mask_bytes(int n_total, int HW) {
     return (size_t)cdiv(HW, F16_BQ) * 4 * tiles * 16 * sizeof(u64);
 }
 
-int aff_filter16_launch(Filter16Args a, void* stream) {
+int aff_filter16_launch(Filter16Args a, int stage, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stage == 1) {
+        hipLaunchKernelGGL(affinity_refine_kernel, dim3(a.HW), dim3(256), 0, s, a);
+        return xmem_check_launch();
+    }
     const int qt = cdiv(a.HW, F16_BQ);
     // two 4-wave workgroups per CU: splits so that query tiles x splits ~ 512, >= 4 tiles per wave
     int sp = 512 / qt; if (sp < 1) sp = 1;
@@ -462,10 +480,7 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     int rc = xmem_check_launch();
     if (rc != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_filter16_kernel, dim3(qt, a.splits), dim3(256), 0, s, a);
-    rc = xmem_check_launch();
-    if (rc != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_scan_kernel, dim3(qt * 4, cdiv(a.total_tiles, SCAN_TILES)), dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_refine_kernel, dim3(a.HW), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(affinity_scan_kernel, dim3(qt * 4, cdiv(a.total_tiles, SCAN_TILES)), dim3(256), 0, s, a);
     return xmem_check_launch();
 }
