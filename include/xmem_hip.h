@@ -186,6 +186,11 @@ int xmem_affinity_topk(const xmem_key_segment* segs_host, int n_seg,
                        float* out_w, int32_t* out_idx, float* out_sim,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Diagnostics for tools (not needed by a caller): byte offsets, inside a workspace sized for (n_total, HW), of the per-query
+ * candidate counts [HW] int32, the per-128-query-tile fallback flags [ceil(HW/128)] int32 and the per-query lower bounds
+ * [HW] float of the last xmem_affinity_topk_hinted call that took the fp16-filter path. */
+int xmem_affinity_debug_offsets(int n_total, int HW, size_t* count_off, size_t* flag_off, size_t* bound_off);
+
 /* Same function with an optional HINT: `idx` are the out_idx [HW][top_k] of an earlier call on the same list of stores (the
  * previous frame of the video), `seg_n` the segment sizes of that call, `grid_w` the width of the stride-16 query grid (0: do not
  * use grid neighbours).  The hint only replaces the sampled pass that bounds the k-th similarity from below (any k distinct

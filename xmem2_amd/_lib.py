@@ -67,6 +67,7 @@ _SIGS = {
     'xmem_nhwc_to_nchw': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'xmem_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'xmem_affinity_topk_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'xmem_affinity_debug_offsets': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     'xmem_affinity_topk': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'xmem_affinity_topk_hinted': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -1112,7 +1112,7 @@ WsLayout ws_layout(int HW, int n_total) {
     w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
     w.rows16_off = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
     w.gcand32_off = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
-    w.gcnt2_off = w.gcand32_off + align_up((size_t)HW * AFW_GCAP * sizeof(int), 256);
+    w.gcnt2_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_cap(n_total) * sizeof(int), 256);
     w.flag_off = w.gcnt2_off + align_up((size_t)HW * sizeof(int), 256);
     w.total = w.flag_off + align_up((size_t)cdiv(HW, AFW_BQ) * sizeof(int), 256);
     return w;
@@ -1122,6 +1122,13 @@ WsLayout ws_layout(int HW, int n_total) {
 extern "C" size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int top_k) {
     if (n_total <= 0 || HW <= 0 || top_k <= 0) return 0;
     return ws_layout(HW, n_total).total;
+}
+
+extern "C" int xmem_affinity_debug_offsets(int n_total, int HW, size_t* count_off, size_t* flag_off, size_t* bound_off) {
+    if (n_total <= 0 || HW <= 0 || !count_off || !flag_off || !bound_off) return XMEM_ERR_BAD_ARG;
+    const WsLayout w = ws_layout(HW, n_total);
+    *count_off = w.gcnt_off; *flag_off = w.flag_off; *bound_off = w.tau_off;
+    return XMEM_OK;
 }
 
 extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg, const float* qk, const float* qe, int Ck, int HW,
@@ -1232,7 +1239,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
             f.splits = 0; f.tiles_per_split = 0;
             f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
             f.rows16 = reinterpret_cast<_Float16*>(ws + wl.rows16_off);
-            f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.flag128 = h.flag128;
+            f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.flag128 = h.flag128; f.lcap = aff_filter16_list_cap(base);
             f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;
             if ((rc = aff_filter16_launch(f, 0, stream)) != XMEM_OK) return rc;             // rows, filter, scan
             w.gcnt = h.gcnt2; w.only = h.flag128;

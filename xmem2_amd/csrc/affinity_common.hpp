@@ -79,11 +79,12 @@ struct Filter16Args {
     _Float16* rows16;                // [N + 32][F16_K] memory operand rows, written by the rows kernel of the same launch
     const float* tau_init;           // [HW] valid lower bound of the exact k-th similarity, or -inf (-> the query is scanned in full)
     u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
-    int* gcand32; int* gcnt;         // [HW][AFW_GCAP] candidate indices, [HW] zeroed by the bound kernel
+    int* gcand32; int* gcnt; int lcap; // [HW][lcap] candidate indices (aff_filter16_list_cap), [HW] zeroed by the bound kernel
     int* flag128;                    // [ceil(HW/128)] zeroed by the bound kernel; set when a list of the tile overflowed (or no bound):
                                      // the fp32 select + merge compute the tile, the refine skips it
     float* out_w; int* out_idx; float* out_sim;
 };
 size_t aff_filter16_mask_bytes(int n_total, int HW);
 size_t aff_filter16_rows_bytes(int n_total);
+int aff_filter16_list_cap(int n_total);
 int aff_filter16_launch(Filter16Args a, int stage, void* stream);   // stage 0: rows, filter, scan;  stage 1: refine

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         else {                                                   // local buffer full: straight to the query's global list
             const int qg = b * 32 + qi;
             const int gs = atomicAdd(&p.gcnt[qg], 1);
-            if (gs < AFW_GCAP) p.gcand32[(size_t)qg * AFW_GCAP + gs] = gi;
+            if (gs < p.lcap) p.gcand32[(size_t)qg * p.lcap + gs] = gi;
             else if (qg < p.HW) p.flag128[qg >> 7] = 1;
         }
     };
@@ -301,13 +301,13 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     if (tid < 32) {
         const int n = min(s_cnt[tid], SCAN_CAP), qg = b * 32 + tid;
         s_base[tid] = (n > 0 && qg < p.HW) ? atomicAdd(&p.gcnt[qg], n) : 0;
-        if (qg < p.HW && s_base[tid] + n > AFW_GCAP) p.flag128[qg >> 7] = 1;    // list overflow: the tile goes to the fp32 select
+        if (qg < p.HW && s_base[tid] + n > p.lcap) p.flag128[qg >> 7] = 1;    // list overflow: the tile goes to the fp32 select
     }
     __syncthreads();
     for (int e = tid; e < 32 * SCAN_CAP; e += 256) {
         const int qi = e / SCAN_CAP, j = e - qi * SCAN_CAP, qg = b * 32 + qi;
-        if (qg < p.HW && j < min(s_cnt[qi], SCAN_CAP) && s_base[qi] + j < AFW_GCAP)
-            p.gcand32[(size_t)qg * AFW_GCAP + s_base[qi] + j] = s_buf[qi][j];
+        if (qg < p.HW && j < min(s_cnt[qi], SCAN_CAP) && s_base[qi] + j < p.lcap)
+            p.gcand32[(size_t)qg * p.lcap + s_base[qi] + j] = s_buf[qi][j];
     }
 }
 
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
         ne[lane] = -e; ke2[lane] = 2.f * (k * e);
     }
     const float bs = p.qmeta[(size_t)q * 4];          // b_sq with the select kernels' arithmetic (bound kernel)
-    const int total = min(p.gcnt[q], AFW_GCAP);       // (a longer list flags the tile)
-    const int* list = p.gcand32 + (size_t)q * AFW_GCAP;
-    // the first round's indices are requested without waiting for the count (the list is AFW_GCAP long; stale entries are
+    const int total = min(p.gcnt[q], p.lcap);       // (a longer list flags the tile)
+    const int* list = p.gcand32 + (size_t)q * p.lcap;
+    // the first round's indices are requested without waiting for the count (the list is lcap >= 2048 long; stale entries are
     // never used: every use is guarded by e < total)
     int gi_next = list[wv * 64 + lane];
     __syncthreads();
@@ -453,6 +453,13 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
             if (p.out_sim) p.out_sim[(size_t)q * p.top_k + r] = v;
         }
     }
+}
+
+// per-query candidate list length: ~N/64 (redundant memories keep thousands of near-ties for a few queries), 2048 .. 16384
+int aff_filter16_list_cap(int n_total) {
+    int c = 2048;
+    while (c < n_total / 64 && c < 16384) c *= 2;
+    return c;
 }
 
 size_t aff_filter16_rows_bytes(int n_total) { return ((size_t)n_total + AFF_ROWS) * F16_K * sizeof(_Float16); }

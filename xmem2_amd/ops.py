@@ -7,6 +7,7 @@ torch is plumbing only: allocation, streams.  No torch compute op is used on the
 import ctypes as C
 import json
 import os
+import sys
 
 import torch
 
@@ -478,6 +479,9 @@ def nchw_to_nhwc(x):
 # memory readout
 # ---------------------------------------------------------------------------------------------
 
+_AFF_STATS = bool(os.environ.get('XMEM_AFFINITY_STATS'))
+
+
 def affinity_topk(segments, qk, qe, top_k, want_sim=False, hint=None):
     """segments: list of (key [n,Ck], shrinkage [n] | None).  Returns w [HW,k], idx [HW,k] (int32), sim | None.
     hint: None or (idx [HW,k'] int32 of an earlier call on the same list of stores, its segment sizes, grid width) - only
@@ -513,6 +517,14 @@ def affinity_topk(segments, qk, qe, top_k, want_sim=False, hint=None):
     check(lib.xmem_affinity_topk_hinted(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, hp, ptr(w), ptr(idx), ptr(sim),
                                         ptr(ws), need, stream_ptr()))
     _tap_end('affinity', e0, 4.0 * ck * n_total * HW)
+    if _AFF_STATS and hp is not None:                      # tools: candidate statistics of the fp16-filter path (synchronises)
+        o = [C.c_size_t(), C.c_size_t(), C.c_size_t()]
+        check(lib.xmem_affinity_debug_offsets(n_total, HW, *[C.byref(x) for x in o]))
+        torch.cuda.synchronize()
+        cnt = ws[o[0].value:o[0].value + 4 * HW].view(torch.int32).float()
+        flg = ws[o[1].value:o[1].value + 4 * ((HW + 127) // 128)].view(torch.int32)
+        print(f'[affinity] N={n_total} HW={HW}: candidates/query mean {float(cnt.mean()):.0f} median {float(cnt.median()):.0f} '
+              f'max {int(cnt.max())}; fallback tiles {int((flg != 0).sum())}/{flg.numel()}', file=sys.stderr)
     if RECORD is not None:
         RECORD.append(('affinity', f'{n_total}x{HW}k{top_k}', 4.0 * ck * n_total * HW,
                        lambda: lib.xmem_affinity_topk_hinted(arr, len(segs), ptr(qk), ptr(qe), ck, HW, top_k, hp, ptr(w), ptr(idx),
