@@ -42,6 +42,8 @@ if ROOT not in sys.path:
 from xmem2_amd.launch import shard_videos, spawn_ranks          # noqa: E402,F401  (shard_videos re-exported for callers)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0          # dense v_mfma_f32_32x32x16_f16 peak (~2.5 PF)
+F16_K = 144                            # contraction length of the fp16 filter (128 terms + 16 augmentation terms)
 CK, CV, TOPK = 64, 512, 30
 BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
 
@@ -535,7 +537,15 @@ def main():
                        'control_plane': backend or 'none'},
             'per_rank_fps': per_rank,
             'roofline': {'bound': 'mfma',
-                         'kernel': 'xmem_affinity_topk: affinity_kernel (fused anisotropic-L2 similarity + exact top-k, fp32 MFMA) + bound / merge kernels',
+                         'kernel': 'xmem_affinity_topk_hinted: bound from the previous frame\'s matches -> fp16 filter on v_mfma_f32_32x32x16_f16 '
+                                   '(augmented operands: the contraction yields a rigorous UPPER estimate; one candidate bit per memory row x query) '
+                                   '-> scan -> exact fp32 refine of ~100 candidates per query.  Outputs bit-identical to the fp32 MFMA select, which '
+                                   'un-hinted calls and query tiles with overflowing candidate lists (scene cuts) still run',
+                         'note': 'achieved = SURVEY 8(d) algorithmic FLOPs of the reference\'s fp32 similarity (4*C_k*N*HW per call) / measured time of '
+                                 'the whole call; peak = dense fp32 MFMA, the pipe the contraction ran on until round 2.  The N x HW contraction now '
+                                 'runs on the fp16 matrix pipe (16x the rate) as a FILTER and only the surviving candidates are evaluated in fp32, '
+                                 'so frac is an fp32-equivalent rate and may exceed 1; per-kernel times and the filter\'s own executed-MFMA fraction '
+                                 'are under "kernels" (from the kernel trace)',
                          'achieved': aff_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': (aff_tflops / PEAK_FP32_MFMA_TFLOPS) if aff_tflops else None, 'traffic': None,
                          'algorithmic_gflop_per_frame': aff_gf, 'ms_per_frame': aff_ms,
@@ -577,6 +587,20 @@ def main():
                 if aff_us:
                     line['roofline']['timed_region_trace_us_per_frame'] = aff_us
                     line['roofline']['frac_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
+                    ks = {}
+                    for k, v in tr['kernels'].items():
+                        if family_of(k) == 'affinity' and v[0]:
+                            ks[k.split('(')[0]] = dict(launches_per_frame=v[0] / st, avg_us=v[1] / v[0] / 1e3, us_per_frame=v[1] / st / 1e3)
+                    fk = next((k for k in ks if 'filter16' in k), None)
+                    if fk:                                   # the filter's own matrix-pipe rate: executed fp16 FLOPs / its time
+                        calls = ks[fk]['launches_per_frame']
+                        n_mem = aff_gf * 1e9 / (4.0 * CK * alg['hw']) / max(aff['calls'] / nf, 1e-9) if aff else 0.0
+                        q_pad = (alg['hw'] + 127) // 128 * 128
+                        gf = 2.0 * n_mem * q_pad * F16_K / 1e9
+                        tf = gf / (ks[fk]['avg_us'] * 1e-3) if ks[fk]['avg_us'] else None
+                        ks[fk].update(executed_gflop_per_launch=gf, executed_tflops=tf, peak_tflops=PEAK_F16_MFMA_TFLOPS,
+                                      frac_of_f16_mfma_peak=(tf / PEAK_F16_MFMA_TFLOPS) if tf else None, calls_per_frame=calls)
+                    line['roofline']['kernels'] = ks
         pmc = committed_pmc(args.workload, args.precision)
         if pmc is not None:
             line['roofline']['traffic'] = pmc['families'].get('affinity')

@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
 __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     __shared__ int s_cnt[32], s_base[32];
     __shared__ int s_buf[32][SCAN_CAP];
+    __shared__ volatile int s_dead;                              // the tile is (being) flagged: nothing more to collect
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    // a flagged 128-query tile is recomputed by the fp32 select: its lists are not needed (after a scene cut nearly every bit
+    // is set - without this exit the scan would push hundreds of millions of candidates through atomics)
+    if (p.flag128[b >> 2] != 0) return;
+    if (tid == 0) s_dead = 0;
     const int t0 = blockIdx.y * SCAN_TILES;
     const int nt = min(SCAN_TILES, p.total_tiles - t0);
     if (tid < 32) s_cnt[tid] = 0;
@@ -255,17 +260,18 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (j >> 5);
         if (row >= sd.n) return;                                 // clamped duplicate of the segment's last row
         const int qi = j & 31, gi = sd.base + row;
-        if (b * 32 + qi >= p.HW) return;                        // padding query of the last tile (only non-finite estimates reach here)
+        if (b * 32 + qi >= p.HW || s_dead) return;              // padding query of the last tile (non-finite estimates) / tile given up
         const int slot = atomicAdd(&s_cnt[qi], 1);
         if (slot < SCAN_CAP) s_buf[qi][slot] = gi;
         else {                                                   // local buffer full: straight to the query's global list
             const int qg = b * 32 + qi;
             const int gs = atomicAdd(&p.gcnt[qg], 1);
             if (gs < p.lcap) p.gcand32[(size_t)qg * p.lcap + gs] = gi;
-            else if (qg < p.HW) p.flag128[qg >> 7] = 1;
+            else { p.flag128[qg >> 7] = 1; s_dead = 1; }
         }
     };
     for (int w0 = tid; w0 - lane < nt * 16; w0 += 4 * 256) {     // wave-uniform trip count
+        if (s_dead) break;                                       // (uniform per wave: one LDS word)
         u64 m[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) m[u] = (w0 + 256 * u < nt * 16) ? words[w0 + 256 * u] : 0ull;
