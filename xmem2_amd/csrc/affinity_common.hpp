@@ -77,7 +77,7 @@ struct Filter16Args {
     const _Float16* qop16;           // [HW][F16_K] query operand rows          } written by the bound kernel
     const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), 0, 0, 0   }
     _Float16* rows16;                // [N + 32][F16_K] memory operand rows, written by the rows kernel of the same launch
-    const float* tau_init;           // [HW] valid lower bound of the exact k-th similarity, or -inf (-> the query is scanned in full)
+    const float* tau_init;           // [HW] valid lower bound of the exact k-th similarity, or -inf (-> its tile is flagged)
     u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
     int* gcand32; int* gcnt; int lcap; // [HW][lcap] candidate indices (aff_filter16_list_cap), [HW] zeroed by the bound kernel
     int* flag128;                    // [ceil(HW/128)] zeroed by the bound kernel; set when a list of the tile overflowed (or no bound):

@@ -1,32 +1,37 @@
-// Exact top-k readout with an fp16 FILTER pass and an exact fp32 REFINE pass (large memories, when a bound hint exists).
+// Exact top-k readout with an fp16 FILTER pass and an exact fp32 REFINE pass (memories of >= 256 tiles, when a bound hint exists).
 //
 // The fp32 select of affinity.hip contracts all N x HW pairs on the fp32 matrix pipe (64 FLOP/clk/SIMD) although only a few
 // dozen pairs per query can end up in the top-k.  Here the N x HW contraction runs on v_mfma_f32_32x32x16_f16 (16x the rate)
-// with operands ROUNDED to fp16, and a rigorous bound eps on |approximate - exact| decides which pairs could still matter:
+// with operands ROUNDED to fp16, and a rigorous bound eps on |approximate - exact| decides which pairs could still matter.
+// With S(n,q) the exact fp32 similarity (memory_util.py:20-37 as the fp32 MFMA select evaluates it) and a(n,q) its fp16 version:
 //
-//   filter:  a(n,q) = fp16 contraction (fp32 accumulate, same formula as memory_util.py:20-37)
-//            |a - S| <= eps(n)   with S the exact value, eps(n) = kappa * (||mk_n^2|| Cmax + ||mk_n|| Dmax) * ms_n / 8  (+ small terms)
-//            [Cauchy-Schwarz over the 2*C_k products, each off by <= 2^-10 relative after two fp16 roundings; Cmax / Dmax are the
-//             largest ||qe||, ||2 qk qe|| of the workgroup's queries; kappa also covers the fp32 accumulation of both passes;
-//             fp16 subnormal operands are NOT flushed by the matrix pipe (tools/probes/f16_denorm_probe.hip), their absolute
-//             rounding error is the F16_ABS term; operands beyond the fp16 range make eps infinite]
-//            tau(q) <= exact k-th similarity (the hint bound)  =>  every element of the exact top-k has a + eps >= tau.
-//            One bit per (memory row, query) pair says "a + eps >= tau"; no lists, no atomics, no synchronisation.
-//   scan:    the bit matrix (N x HW / 8 bytes, ~0.2 % set) is turned into one index list per query.
-//   refine:  the listed candidates (~100 per query) are re-evaluated EXACTLY in fp32 with the same fmaf chain the fp32 MFMA
-//            select executes (bit-identical values), ranked, and soft-maxed as the merge kernel does - the outputs are
-//            bit-identical to the fp32 path's.  A query whose list overflows (or that has no bound) is scanned in full by
-//            its refine wave, exactly.
+//   |a - S| <= eps(n,q) = [ KAPPA (||x_n^2|| ||e_q|| + ||x_n|| ||2 k_q e_q||) + ACC |b_sq(q)| + ABS (norms) ] * |ms_n| / 8
+//       Cauchy-Schwarz over the 2 C_k products, each off by <= 2^-10 (1 + 2^-12) relative after two fp16 roundings (KAPPA adds
+//       the fp32 accumulation of both evaluations, ACC the same on b_sq which rides in the accumulator); fp16 SUBNORMAL operands
+//       are not flushed by the matrix pipe (tools/probes/f16_denorm_probe.hip), their absolute rounding error is the ABS term;
+//       an operand beyond the fp16 range, or NaN, makes eps infinite.
+//
+// rows:    one fp16 operand row per memory element, [ms/8 x^2 | ms/8 x | 16 augmentation terms] (affinity_common.hpp); the
+//          query rows [-e | 2ke | ...] come from the bound kernel.  The augmentation terms make the fp32-accumulated dot product
+//          of a memory row and a query row equal to  a(n,q) + eps(n,q)  DIRECTLY (b_sq split hi/lo, eps as products of row and
+//          query factors): the contraction yields an upper estimate of S, the epilogue is one compare.
+// filter:  tau(q) <= exact k-th similarity (the hint bound)  =>  every element of the exact top-k has a + eps >= tau.
+//          One bit per (memory row, query) pair says so; no lists, no atomics, no synchronisation.
+// scan:    the bit matrix (N x HW / 8 bytes, ~0.2 % set) becomes one index list per query.  A list that overflows (no usable
+//          bound: scene cut, garbage hint, hostile ties) flags its 128-query tile.
+// refine:  the listed candidates (~100 per query) are re-evaluated EXACTLY in fp32 with the fmaf chain the fp32 MFMA select
+//          executes (bit-identical values), ranked, and soft-maxed as the merge kernel does: outputs bit-identical to the fp32
+//          path's.  Flagged tiles are computed by the fp32 select + merge of the same launch (affinity.hip), not here.
 #include "affinity_common.hpp"
-#ifndef F16_DBG
-#define F16_DBG 0      // 1 prologue only, 2 no tile loads after the first, 3 loads only, 4 no mask stores
-#endif
-#ifndef SC_DBG
-#define SC_DBG 0      // timing experiments only (tools/probes/filter_ab.sh)
-#endif
 
 #define F16_BQ 128             // queries per filter workgroup (4 blocks of 32)
 #define F16_WAVES 4
+#ifndef F16_WG_PER_CU
+#define F16_WG_PER_CU 2       // filter workgroups (4 waves) per CU the register budget is set for
+#endif
+#ifndef RF_WAVES
+#define RF_WAVES 4           // waves of a refine workgroup (one query)
+#endif
 #define F16_LDB 304            // bytes per query operand row in LDS (288 + 16: odd multiple of 16 B)
 
 // the exact similarity of ONE (row, query) pair: the fmaf chain of the fp32 MFMA select (affinity_wide_kernel):
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void affinity_rows16_kernel(Filter16Args p, in
 // grid (query tiles of 128, splits of the memory), 4 waves; wave w of split s takes tiles t_begin + w, + 4, ...
 // Per 32-row tile and 32-query block: 9 x v_mfma_f32_32x32x16_f16 give the UPPER estimates directly (augmented operands),
 // then 16 compares against tau whose lane masks ARE the output words.
-__global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args p) {
+__global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(Filter16Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char Bh[F16_BQ * F16_LDB];
     __shared__ float s_tau[F16_BQ];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -131,9 +136,6 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
     }
     __syncthreads();
 
-#if F16_DBG == 1
-    return;
-#endif
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
 
@@ -165,13 +167,6 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
         const unsigned char* bq = Bh + boff;
         f32x16 c[4];
         h16x8 bc[4], bn[4];
-#if F16_DBG == 3
-        { float acc = 0.f;
-#pragma unroll
-          for (int t = 0; t < 9; ++t) acc += (float)a[t][0];
-          if (acc == 123.456f) p.gcnt[0] = 1; }
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) bc[i] = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB);
 #pragma unroll
@@ -195,13 +190,6 @@ __global__ __launch_bounds__(256, 2) void affinity_filter16_kernel(Filter16Args 
 #pragma unroll
             for (int i = 0; i < 4; ++i) bc[i] = bn[i];
         }
-#if F16_DBG == 5
-        { float acc = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc += c[i][0] + c[i][5] + c[i][10] + c[i][15];
-          if (acc == 123.456f) p.gcnt[0] = 1; }
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int mlo = 0, mhi = 0;                                   // lane r < 16 collects word r
@@ -301,9 +289,6 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         }
     }
     __syncthreads();
-#if SC_DBG == 2
-    return;
-#endif
     if (tid < 32) {
         const int n = min(s_cnt[tid], SCAN_CAP), qg = b * 32 + tid;
         s_base[tid] = (n > 0 && qg < p.HW) ? atomicAdd(&p.gcnt[qg], n) : 0;
@@ -318,15 +303,18 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
 }
 
 // ============================================================ refine ===================================================
-// One workgroup (4 waves) per query: exact similarities of its candidates (or of ALL memory elements when the list overflowed
-// or no bound existed), 64 per wave and round, each wave keeping a running list of its best by counting ranks; wave 0 merges
-// the four lists and applies the softmax exactly as affinity_merge16_kernel computes it.
+// One workgroup (4 waves) per query: exact similarities of its candidates, 64 per wave and round, each wave keeping a running
+// list of its best (bitwise-descent selection + counting ranks); wave 0 merges the four lists and applies the softmax exactly
+// as affinity_merge16_kernel computes it.
 #define RF_BUF 256             // running list of a wave: compacted to the best top_k whenever another 64 might not fit
-__global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
+#ifndef RF_MINWG
+#define RF_MINWG 1
+#endif
+__global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kernel(Filter16Args p) {
     constexpr int CK = 64;
     __shared__ __attribute__((aligned(16))) float s_op[2 * CK];
-    __shared__ __attribute__((aligned(16))) u64 s_keys[4][RF_BUF + 2];
-    __shared__ int s_n[4];
+    __shared__ __attribute__((aligned(16))) u64 s_keys[RF_WAVES][RF_BUF + 2];
+    __shared__ int s_n[RF_WAVES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x;
     if (p.flag128[q >> 7]) return;                    // computed by the fp32 select + merge of this launch
@@ -413,10 +401,10 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
 
     int cnt = 0;
     float thr = -INFINITY;                            // raised to the wave's k-th best once it knows k candidates
-    for (int b0 = wv * 64; b0 < total; b0 += 256) {
+    for (int b0 = wv * 64; b0 < total; b0 += 64 * RF_WAVES) {
         const int e = b0 + lane;
         const int gi = gi_next;
-        if (e + 256 < total) gi_next = list[e + 256];       // next round's index in flight under this round
+        if (e + 64 * RF_WAVES < total) gi_next = list[e + 64 * RF_WAVES];       // next round's index in flight under this round
         bool pass = false; float s = 0.f;
         if (e < total) {
             const SegDev sd = seg_of_row(p, gi);
@@ -439,7 +427,7 @@ __global__ __launch_bounds__(256) void affinity_refine_kernel(Filter16Args p) {
         if (lane == 0) s_n[wv] = cnt;
         __syncthreads();
         if (wv != 0) return;
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < RF_WAVES; ++w) {
             const int nw = s_n[w];
             if (lane < nw) keys[cnt + lane] = s_keys[w][lane];
             cnt += nw;
@@ -478,12 +466,12 @@ size_t aff_filter16_mask_bytes(int n_total, int HW) {
 int aff_filter16_launch(Filter16Args a, int stage, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (stage == 1) {
-        hipLaunchKernelGGL(affinity_refine_kernel, dim3(a.HW), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(affinity_refine_kernel, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
         return xmem_check_launch();
     }
     const int qt = cdiv(a.HW, F16_BQ);
     // two 4-wave workgroups per CU: splits so that query tiles x splits ~ 512, >= 4 tiles per wave
-    int sp = 512 / qt; if (sp < 1) sp = 1;
+    int sp = (256 * F16_WG_PER_CU) / qt; if (sp < 1) sp = 1;
     { int maxs = a.total_tiles / (4 * F16_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
     a.tiles_per_split = cdiv(a.total_tiles, sp);
     a.splits = cdiv(a.total_tiles, a.tiles_per_split);
