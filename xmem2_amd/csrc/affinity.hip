@@ -738,7 +738,7 @@ struct HintArgs {
     const float* qk; const float* qe; int HW, top_k;
     float* tau0; int* gcnt; int* ovf;
     _Float16* qop16; float* qmeta;       // optional: query operands of the fp16 filter (affinity_filter.hip)
-    int* gcnt2; int* flag128;            // optional: second list counters / per-128-query-tile fallback flags, zeroed here
+    int* flag1; int* flag2;              // optional: per-128-query-tile flags of the two filter passes, zeroed here
 };
 #define HINT_MAXC 320       // 5 queries x 64 indices
 #define HINT_NB 12          // entries taken from each grid neighbour's list
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
     for (int i = 0; i < 8; ++i) tab[lane + 64 * i] = -1;
     if (lane == 0) {
         p.gcnt[q] = 0; if ((q & 63) == 0) p.ovf[q >> 6] = 0;
-        if (p.gcnt2) { p.gcnt2[q] = 0; if ((q & 127) == 0) p.flag128[q >> 7] = 0; }
+        if (p.flag1 && (q & 127) == 0) { p.flag1[q >> 7] = 0; p.flag2[q >> 7] = 0; }
     }
     // candidate lists: this query and its grid neighbours in the hint
     int nq[5]; int nn = 0;
@@ -1114,7 +1114,7 @@ WsLayout ws_layout(int HW, int n_total) {
     w.gcand32_off = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
     w.gcnt2_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_cap(n_total) * sizeof(int), 256);
     w.flag_off = w.gcnt2_off + align_up((size_t)HW * sizeof(int), 256);
-    w.total = w.flag_off + align_up((size_t)cdiv(HW, AFW_BQ) * sizeof(int), 256);
+    w.total = w.flag_off + align_up((size_t)2 * cdiv(HW, AFW_BQ) * sizeof(int), 256);
     return w;
 }
 }  // namespace
@@ -1127,7 +1127,7 @@ extern "C" size_t xmem_affinity_topk_workspace_bytes(int n_total, int HW, int to
 extern "C" int xmem_affinity_debug_offsets(int n_total, int HW, size_t* count_off, size_t* flag_off, size_t* bound_off) {
     if (n_total <= 0 || HW <= 0 || !count_off || !flag_off || !bound_off) return XMEM_ERR_BAD_ARG;
     const WsLayout w = ws_layout(HW, n_total);
-    *count_off = w.gcnt_off; *flag_off = w.flag_off; *bound_off = w.tau_off;
+    *count_off = w.gcnt_off; *flag_off = w.flag_off; *bound_off = w.tau_off;     // flags: [pass 1 | pass 2], ceil(HW/128) each
     return XMEM_OK;
 }
 
@@ -1224,36 +1224,22 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         const bool use16 = aff_use_filter16();
         h.qop16 = use16 ? reinterpret_cast<_Float16*>(ws + wl.qop16_off) : nullptr;
         h.qmeta = use16 ? reinterpret_cast<float*>(ws + wl.qmeta_off) : nullptr;
-        h.gcnt2 = use16 ? reinterpret_cast<int*>(ws + wl.gcnt2_off) : nullptr;
-        h.flag128 = use16 ? reinterpret_cast<int*>(ws + wl.flag_off) : nullptr;
+        h.flag1 = use16 ? reinterpret_cast<int*>(ws + wl.flag_off) : nullptr;
+        h.flag2 = use16 ? h.flag1 + cdiv(HW, AFW_BQ) : nullptr;
         hipLaunchKernelGGL(affinity_hint_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), 0, s, h);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         if (use16) {
-            // fp16 filter + exact fp32 refine (affinity_filter.hip): same outputs as the fp32 select below, bit for bit.
-            // Query tiles whose candidate lists overflow (no usable bound: scene cut, garbage hint) are flagged by the scan and
-            // taken by the fp32 select (self-tightening lists, bound = the hint's) + merge; those two launches return at once
-            // for every other tile, the refine skips the flagged ones.
+            // fp16 filter + exact fp32 refine (affinity_filter.hip): same outputs as the fp32 select below, bit for bit
             Filter16Args f;
             for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) f.seg[i] = a.seg[i];
             f.n_seg = ns; f.total_tiles = tiles; f.qk = qk; f.qe = qe; f.HW = HW; f.top_k = top_k;
             f.splits = 0; f.tiles_per_split = 0;
             f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
             f.rows16 = reinterpret_cast<_Float16*>(ws + wl.rows16_off);
-            f.tau_init = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.flag128 = h.flag128; f.lcap = aff_filter16_list_cap(base);
+            f.tau = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.lcap = aff_filter16_list_cap(base);
+            f.flag1 = h.flag1; f.flag2 = h.flag2; f.only = nullptr; f.flag_out = nullptr;
             f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;
-            if ((rc = aff_filter16_launch(f, 0, stream)) != XMEM_OK) return rc;             // rows, filter, scan
-            w.gcnt = h.gcnt2; w.only = h.flag128;
-            const size_t lds = ((size_t)AFW_BQ * AFF_LDB + 3 * AFW_BQ + 4) * sizeof(float) + (size_t)AFW_BQ * AFW_CAP * sizeof(u64);
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
-            hipLaunchKernelGGL(affinity_wide_kernel, dim3(qt128, w.splits), dim3(512), lds, s, w);
-            if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-            int hc = w.splits * (top_k > 32 ? top_k : 32);
-            if (hc > AFW_GCAP) hc = AFW_GCAP;
-            hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), (size_t)4 * (hc + 2) * sizeof(u64), s, gcand, h.gcnt2,
-                               ovf, a.part_key, a.part_cnt, 0, HW, top_k, hc, out_w, out_idx, out_sim, (const int*)h.flag128);
-            if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-            return aff_filter16_launch(f, 1, stream);                                       // refine
+            return aff_filter16_launch(f, stream);
         }
     } else {
         // sampled bound pass: every 4th 32-row tile (every 8th for very large chunk-dealt memories)

@@ -77,14 +77,19 @@ struct Filter16Args {
     const _Float16* qop16;           // [HW][F16_K] query operand rows          } written by the bound kernel
     const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), 0, 0, 0   }
     _Float16* rows16;                // [N + 32][F16_K] memory operand rows, written by the rows kernel of the same launch
-    const float* tau_init;           // [HW] valid lower bound of the exact k-th similarity, or -inf (-> its tile is flagged)
+    float* tau;                      // [HW] valid lower bound of the exact k-th similarity (-inf: none yet); raised by the tighten pass
     u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
     int* gcand32; int* gcnt; int lcap; // [HW][lcap] candidate indices (aff_filter16_list_cap), [HW] zeroed by the bound kernel
-    int* flag128;                    // [ceil(HW/128)] zeroed by the bound kernel; set when a list of the tile overflowed (or no bound):
-                                     // the fp32 select + merge compute the tile, the refine skips it
+    // Two passes.  Pass 1 (only == nullptr) lists every query; a list that overflows (bound too loose: scene cut, first frames,
+    // garbage hint) sets flag1 of its 128-query tile.  The tighten launch turns the partial lists of flagged tiles into a real
+    // bound (k-th best EXACT similarity of the listed elements), pass 2 (only == flag1) filters and lists those tiles again.
+    // A list that still overflows (exact ties by the thousand) sets flag2: the refine scans that query's tile in full.
+    int* flag1; int* flag2;          // [ceil(HW/128)] each, zeroed by the bound kernel
+    const int* only;                 // filter / scan / tighten: restrict to tiles whose flag is set (nullptr: all tiles)
+    int* flag_out;                   // scan: where an overflow is recorded (flag1 in pass 1, flag2 in pass 2)
     float* out_w; int* out_idx; float* out_sim;
 };
 size_t aff_filter16_mask_bytes(int n_total, int HW);
 size_t aff_filter16_rows_bytes(int n_total);
 int aff_filter16_list_cap(int n_total);
-int aff_filter16_launch(Filter16Args a, int stage, void* stream);   // stage 0: rows, filter, scan;  stage 1: refine
+int aff_filter16_launch(Filter16Args a, void* stream);            // rows, filter, scan, tighten, filter, scan, refine

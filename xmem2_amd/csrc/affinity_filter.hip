@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(F
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
+    if (p.only && p.only[blockIdx.x] == 0) return;              // pass 2: flagged query tiles only
     const int q0 = blockIdx.x * F16_BQ;
     const int split = blockIdx.y;
 
@@ -124,15 +125,8 @@ __global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(F
     }
     if (tid < F16_BQ) {
         const int qg = q0 + tid;
-        float t0 = INFINITY;
-        if (qg < p.HW) {
-            t0 = p.tau_init[qg];
-            if (t0 == -INFINITY) {                                   // no bound: the tile goes to the fp32 select
-                if (split == 0) p.flag128[qg >> 7] = 1;
-                t0 = INFINITY;
-            }
-        }
-        s_tau[tid] = t0;
+        // a query without a bound (-inf) keeps every pair: its list fills up, flags the tile, and the tighten pass makes a bound
+        s_tau[tid] = qg < p.HW ? p.tau[qg] : INFINITY;
     }
     __syncthreads();
 
@@ -229,33 +223,45 @@ __global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(F
 __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     __shared__ int s_cnt[32], s_base[32];
     __shared__ int s_buf[32][SCAN_CAP];
-    __shared__ volatile int s_dead;                              // the tile is (being) flagged: nothing more to collect
+    __shared__ volatile int s_full[32];                          // the query's global list is full (or it is a padding query)
+    __shared__ int s_nfull;
+    __shared__ volatile int s_dead;                              // every list of this block is full: nothing more to collect
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    // a flagged 128-query tile is recomputed by the fp32 select: its lists are not needed (after a scene cut nearly every bit
-    // is set - without this exit the scan would push hundreds of millions of candidates through atomics)
-    if (p.flag128[b >> 2] != 0) return;
-    if (tid == 0) s_dead = 0;
+    if (p.only && p.only[b >> 2] == 0) return;                   // pass 2: flagged query tiles only
     const int t0 = blockIdx.y * SCAN_TILES;
     const int nt = min(SCAN_TILES, p.total_tiles - t0);
-    if (tid < 32) s_cnt[tid] = 0;
+    if (tid == 0) { s_dead = 0; s_nfull = 0; }
+    __syncthreads();
+    if (tid < 32) {
+        // lists filled by workgroups that ran earlier need nothing from this one (after a scene cut nearly every bit is set:
+        // without these exits the scan would push hundreds of millions of candidates through atomics)
+        const int qg = b * 32 + tid;
+        const bool full = qg >= p.HW || p.gcnt[qg] >= p.lcap;
+        s_cnt[tid] = 0; s_full[tid] = full;
+        if (full && atomicAdd(&s_nfull, 1) == 31) s_dead = 1;
+    }
     __syncthreads();
     const u64* words = p.mask + ((size_t)b * p.total_tiles + t0) * 16;
     const int lane = tid & 63;
     auto insert = [&](int w, int j) {                            // bit j of word w (relative to this slice)
+        const int qi = j & 31;
+        if (s_full[qi]) return;
         const int tile = t0 + (w >> 4), r = w & 15;
         const SegDev sd = seg_of_tile(p, tile);
         const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (j >> 5);
         if (row >= sd.n) return;                                 // clamped duplicate of the segment's last row
-        const int qi = j & 31, gi = sd.base + row;
-        if (b * 32 + qi >= p.HW || s_dead) return;              // padding query of the last tile (non-finite estimates) / tile given up
+        const int gi = sd.base + row;
         const int slot = atomicAdd(&s_cnt[qi], 1);
         if (slot < SCAN_CAP) s_buf[qi][slot] = gi;
         else {                                                   // local buffer full: straight to the query's global list
             const int qg = b * 32 + qi;
             const int gs = atomicAdd(&p.gcnt[qg], 1);
             if (gs < p.lcap) p.gcand32[(size_t)qg * p.lcap + gs] = gi;
-            else { p.flag128[qg >> 7] = 1; s_dead = 1; }
+            if (gs + 1 >= p.lcap) {                              // a list that reaches its capacity counts as overflowed
+                p.flag_out[qg >> 7] = 1;
+                if (atomicExch(const_cast<int*>(&s_full[qi]), 1) == 0 && atomicAdd(&s_nfull, 1) == 31) s_dead = 1;   // counted once
+            }
         }
     };
     for (int w0 = tid; w0 - lane < nt * 16; w0 += 4 * 256) {     // wave-uniform trip count
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     if (tid < 32) {
         const int n = min(s_cnt[tid], SCAN_CAP), qg = b * 32 + tid;
         s_base[tid] = (n > 0 && qg < p.HW) ? atomicAdd(&p.gcnt[qg], n) : 0;
-        if (qg < p.HW && s_base[tid] + n > p.lcap) p.flag128[qg >> 7] = 1;    // list overflow: the tile goes to the fp32 select
+        if (n > 0 && qg < p.HW && s_base[tid] + n >= p.lcap) p.flag_out[qg >> 7] = 1;      // list overflow (reaching the capacity counts)
     }
     __syncthreads();
     for (int e = tid; e < 32 * SCAN_CAP; e += 256) {
@@ -310,6 +316,9 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
 #ifndef RF_MINWG
 #define RF_MINWG 1
 #endif
+// TIGHTEN = true (between the two passes, flagged tiles only): instead of the outputs, the k-th best exact similarity of the
+// listed elements becomes the query's bound (valid: k real elements reach it) and its list is emptied for pass 2.
+template <bool TIGHTEN>
 __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kernel(Filter16Args p) {
     constexpr int CK = 64;
     __shared__ __attribute__((aligned(16))) float s_op[2 * CK];
@@ -317,7 +326,9 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
     __shared__ int s_n[RF_WAVES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x;
-    if (p.flag128[q >> 7]) return;                    // computed by the fp32 select + merge of this launch
+    if (TIGHTEN && p.flag1[q >> 7] == 0) return;
+    // a list that overflowed even with the tightened bound (thousands of exact ties): every memory element is evaluated
+    const bool full = !TIGHTEN && p.flag2[q >> 7] != 0 && p.gcnt[q] >= p.lcap;
     float* ne = s_op; float* ke2 = s_op + CK; u64* keys = s_keys[wv];
     if (wv == 0) {
         const float k = p.qk[(size_t)q * CK + lane];
@@ -325,11 +336,12 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
         ne[lane] = -e; ke2[lane] = 2.f * (k * e);
     }
     const float bs = p.qmeta[(size_t)q * 4];          // b_sq with the select kernels' arithmetic (bound kernel)
-    const int total = min(p.gcnt[q], p.lcap);       // (a longer list flags the tile)
+    int total = min(p.gcnt[q], p.lcap);
+    if (full) { total = 0; for (int i = 0; i < p.n_seg; ++i) total += p.seg[i].n; }
     const int* list = p.gcand32 + (size_t)q * p.lcap;
     // the first round's indices are requested without waiting for the count (the list is lcap >= 2048 long; stale entries are
     // never used: every use is guarded by e < total)
-    int gi_next = list[wv * 64 + lane];
+    int gi_next = full ? wv * 64 + lane : list[wv * 64 + lane];
     __syncthreads();
 
     // The best min(n, keepn) of keys[0..n) move to the front in descending order; returns the new length.  n <= RF_BUF, keepn <= 64.
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
     for (int b0 = wv * 64; b0 < total; b0 += 64 * RF_WAVES) {
         const int e = b0 + lane;
         const int gi = gi_next;
-        if (e + 64 * RF_WAVES < total) gi_next = list[e + 64 * RF_WAVES];       // next round's index in flight under this round
+        if (e + 64 * RF_WAVES < total) gi_next = full ? e + 64 * RF_WAVES : list[e + 64 * RF_WAVES];       // next round's index in flight under this round
         bool pass = false; float s = 0.f;
         if (e < total) {
             const SegDev sd = seg_of_row(p, gi);
@@ -435,6 +447,13 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
         __builtin_amdgcn_wave_barrier();
     } else if (wv != 0) return;
     cnt = compact(cnt, p.top_k);
+    if (TIGHTEN) {
+        if (lane == 0) {
+            if (cnt >= p.top_k) p.tau[q] = fmaxf(p.tau[q], key_val(keys[p.top_k - 1]));
+            p.gcnt[q] = 0;
+        }
+        return;
+    }
     // softmax without max shift (memory_util.py:48-49), summed exactly as affinity_merge16_kernel: 16 lanes, r = l, l+16, ...
     if (lane < 16) {
         float sum = 0.f;
@@ -463,12 +482,8 @@ size_t aff_filter16_mask_bytes(int n_total, int HW) {
     return (size_t)cdiv(HW, F16_BQ) * 4 * tiles * 16 * sizeof(u64);
 }
 
-int aff_filter16_launch(Filter16Args a, int stage, void* stream) {
+int aff_filter16_launch(Filter16Args a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (stage == 1) {
-        hipLaunchKernelGGL(affinity_refine_kernel, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
-        return xmem_check_launch();
-    }
     const int qt = cdiv(a.HW, F16_BQ);
     // two 4-wave workgroups per CU: splits so that query tiles x splits ~ 512, >= 4 tiles per wave
     int sp = (256 * F16_WG_PER_CU) / qt; if (sp < 1) sp = 1;
@@ -477,11 +492,25 @@ int aff_filter16_launch(Filter16Args a, int stage, void* stream) {
     a.splits = cdiv(a.total_tiles, a.tiles_per_split);
     int n_total = 0;
     for (int i = 0; i < a.n_seg; ++i) n_total += a.seg[i].n;
+    const dim3 fgrid(qt, a.splits), sgrid(qt * 4, cdiv(a.total_tiles, SCAN_TILES));
+    int rc;
     hipLaunchKernelGGL(affinity_rows16_kernel, dim3(cdiv(n_total, 16)), dim3(256), 0, s, a, n_total);
-    int rc = xmem_check_launch();
-    if (rc != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_filter16_kernel, dim3(qt, a.splits), dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_scan_kernel, dim3(qt * 4, cdiv(a.total_tiles, SCAN_TILES)), dim3(256), 0, s, a);
+    // pass 1: every tile, the caller's bound
+    a.only = nullptr; a.flag_out = a.flag1;
+    hipLaunchKernelGGL(affinity_filter16_kernel, fgrid, dim3(256), 0, s, a);
+    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    hipLaunchKernelGGL(affinity_scan_kernel, sgrid, dim3(256), 0, s, a);
+    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    // pass 2: tiles with an overflowed list, with the bound their partial lists give (these three launches return at once
+    // when nothing is flagged - the normal frame)
+    a.only = a.flag1; a.flag_out = a.flag2;
+    hipLaunchKernelGGL(affinity_refine_kernel<true>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
+    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    hipLaunchKernelGGL(affinity_filter16_kernel, fgrid, dim3(256), 0, s, a);
+    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    hipLaunchKernelGGL(affinity_scan_kernel, sgrid, dim3(256), 0, s, a);
+    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    hipLaunchKernelGGL(affinity_refine_kernel<false>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
     return xmem_check_launch();
 }
