@@ -187,14 +187,16 @@ int xmem_affinity_topk(const xmem_key_segment* segs_host, int n_seg,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Diagnostics for tools (not needed by a caller): byte offsets, inside a workspace sized for (n_total, HW), of the per-query
- * candidate counts [HW] int32, the per-128-query-tile fallback flags [ceil(HW/128)] int32 and the per-query lower bounds
- * [HW] float of the last xmem_affinity_topk_hinted call that took the fp16-filter path. */
+ * candidate counts [HW] int32, the per-128-query-tile flags of the two filter passes [2][ceil(HW/128)] int32 and the per-query
+ * lower bounds [HW] float of the last xmem_affinity_topk_hinted call that took the fp16-filter path. */
 int xmem_affinity_debug_offsets(int n_total, int HW, size_t* count_off, size_t* flag_off, size_t* bound_off);
 
 /* Same function with an optional HINT: `idx` are the out_idx [HW][top_k] of an earlier call on the same list of stores (the
  * previous frame of the video), `seg_n` the segment sizes of that call, `grid_w` the width of the stride-16 query grid (0: do not
- * use grid neighbours).  The hint only replaces the sampled pass that bounds the k-th similarity from below (any k distinct
- * elements give a valid bound; the previous frame's matches give a tight one): results are identical with and without it.
+ * use grid neighbours).  The hint only bounds the k-th similarity from below (any k distinct elements give a valid bound; the
+ * previous frame's matches give a tight one): results are bit-identical with and without it.  With a bound (and >= 8192 memory
+ * elements) the N x HW contraction runs on the fp16 matrix pipe as a rigorously bounded filter and only the surviving
+ * candidates are evaluated in fp32, with the arithmetic of the fp32 select (csrc/affinity_filter.hip).
  * hint == NULL behaves as xmem_affinity_topk.  The reference recomputes everything per frame (memory_manager.py:82-120). */
 typedef struct {
     const int32_t* idx; int top_k;

@@ -482,7 +482,6 @@ struct WideArgs {
     const float* tau_init;           // [HW] valid lower bound of the k-th similarity (-inf: no bound -> tile goes to the safe kernel)
     u64* gcand; int* gcnt;           // [HW][AFW_GCAP], [HW] (zeroed by the bound kernels)
     int* ovf;                        // [ceil(HW/64)]
-    const int* only;                 // optional [ceil(HW/128)]: workgroups of query tiles whose flag is 0 return at once
 };
 
 __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
@@ -498,7 +497,6 @@ __global__ __launch_bounds__(512, 1) void affinity_wide_kernel(WideArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    if (p.only && p.only[blockIdx.x] == 0) return;    // fp16-filter launches: only the query tiles whose candidate lists overflowed
     const int q0 = blockIdx.x * AFW_BQ;
     const int split = blockIdx.y;
     const int keep = p.top_k > 32 ? p.top_k : 32;     // entries a list is cut back to (>= top_k)
@@ -916,8 +914,7 @@ __global__ __launch_bounds__(256) void affinity_merge16_kernel(const u64* __rest
                                                                const int* __restrict__ ovf, const u64* __restrict__ part_key,
                                                                const int* __restrict__ part_cnt, int fsplits, int HW, int top_k,
                                                                int heavy_cap, float* __restrict__ out_w, int* __restrict__ out_idx,
-                                                               float* __restrict__ out_sim, const int* __restrict__ only) {
-    if (only && only[(blockIdx.x * 16) >> 7] == 0) return;     // fp16-filter launches: flagged 128-query tiles only
+                                                               float* __restrict__ out_sim) {
     __shared__ __attribute__((aligned(16))) u64 s_keys[16][AFM_LIGHT + 2];
     extern __shared__ __attribute__((aligned(16))) u64 s_heavy_dyn[];        // [4][heavy_cap + 2]: the longest list a query can have
     __shared__ float s_v[16][AFF_MAX_TOPK];
@@ -1090,7 +1087,7 @@ inline bool aff_use_filter16() {
     return !(e && e[0] == '0');
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, rows16_off, gcand32_off, gcnt2_off, flag_off, total; int fsplits; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, rows16_off, gcand32_off, flag_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
 #define AFF_FB_GRID 128     // persistent workgroups of the safe fallback pass (a scene cut flags every tile: ~0.7 ms at B32)
 inline int fallback_splits(int HW) { (void)HW; return 16; }
@@ -1112,8 +1109,7 @@ WsLayout ws_layout(int HW, int n_total) {
     w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
     w.rows16_off = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
     w.gcand32_off = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
-    w.gcnt2_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_cap(n_total) * sizeof(int), 256);
-    w.flag_off = w.gcnt2_off + align_up((size_t)HW * sizeof(int), 256);
+    w.flag_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_cap(n_total) * sizeof(int), 256);
     w.total = w.flag_off + align_up((size_t)2 * cdiv(HW, AFW_BQ) * sizeof(int), 256);
     return w;
 }
@@ -1190,7 +1186,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     WideArgs w;
     for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) w.seg[i] = a.seg[i];
     w.n_seg = ns; w.total_tiles = tiles; w.qk = qk; w.qe = qe; w.HW = HW; w.top_k = top_k;
-    w.tau_init = tau0; w.gcand = gcand; w.gcnt = gcnt; w.ovf = ovf; w.only = nullptr;
+    w.tau_init = tau0; w.gcand = gcand; w.gcnt = gcnt; w.ovf = ovf;
     // one 8-wave workgroup per CU: splits so that query tiles x splits fills (at most) the 256 CUs, >= 8 tiles per wave
     int sp = 256 / qt128; if (sp < 1) sp = 1;
     { int maxs = tiles / (8 * AFW_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
@@ -1266,7 +1262,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     int heavy_cap = w.splits * (top_k > 32 ? top_k : 32);          // every workgroup hands over at most max(top_k, 32) entries
     if (heavy_cap > AFW_GCAP) heavy_cap = AFW_GCAP;
     hipLaunchKernelGGL(affinity_merge16_kernel, dim3(cdiv(HW, 16)), dim3(256), (size_t)4 * (heavy_cap + 2) * sizeof(u64), s, gcand, gcnt,
-                       ovf, a.part_key, a.part_cnt, 0, HW, top_k, heavy_cap, out_w, out_idx, out_sim, (const int*)nullptr);
+                       ovf, a.part_key, a.part_cnt, 0, HW, top_k, heavy_cap, out_w, out_idx, out_sim);
     return xmem_check_launch();
 }
 
