@@ -250,3 +250,26 @@ def test_deterministic_augmentations_host_side():
         assert (p != t).sum() <= 0.03 * t.sum(), kw                                         # same geometry in both backends
     moved = affine_tensor(mask[0:1], translate=(12, 0))[0]
     assert torch.equal(moved[:, 12:], mask[0][:, :-12]) and float(moved[:, :12].sum()) == 0
+
+
+def test_affinity_workspace_layout_is_consistent():
+    """Host-only entry points of the readout select: the workspace covers the regions the diagnostics name, grows with the
+    memory (bit matrix, fp16 operand rows, candidate lists) and rejects bad arguments."""
+    import ctypes as C
+    from xmem2_amd._lib import load
+    lib = load()
+    sizes = []
+    for n, hw in ((51840, 1620), (936000, 3600), (4177920, 8160)):
+        total = lib.xmem_affinity_topk_workspace_bytes(n, hw, 30)
+        o = [C.c_size_t(), C.c_size_t(), C.c_size_t()]
+        assert lib.xmem_affinity_debug_offsets(n, hw, *[C.byref(x) for x in o]) == 0
+        cnt, flag, bound = (x.value for x in o)
+        assert cnt % 256 == 0 and flag % 256 == 0 and bound % 256 == 0
+        assert cnt + 4 * hw <= total and bound + 4 * hw <= total and flag + 8 * ((hw + 127) // 128) <= total
+        rows16 = (n + 32) * 144 * 2                                    # fp16 operand rows of the filter
+        bits = ((hw + 127) // 128) * 4 * ((n + 31) // 32) * 128      # one candidate bit per (row, query), 32-row x 32-query words
+        assert total >= rows16 + bits
+        sizes.append(total)
+    assert sizes[0] < sizes[1] < sizes[2]
+    assert lib.xmem_affinity_topk_workspace_bytes(0, 1620, 30) == 0
+    assert lib.xmem_affinity_debug_offsets(0, 1620, None, None, None) != 0
