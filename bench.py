@@ -149,8 +149,6 @@ def run_gpu(args, device, rank, world):
     from xmem2_amd.run_on_video import AsyncMaskFetcher
     from xmem2_amd.synth import synthetic_state_dict
     wl = WORKLOADS[args.workload]
-    if os.environ.get('XMEM_BENCH_MAIN_PRIORITY'):     # experiment: the frame loop on a high-priority stream (side stream stays at 0)
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=int(os.environ['XMEM_BENCH_MAIN_PRIORITY'])))
     cfg = workload_config(wl)
     sd = synthetic_state_dict(0)
     net = XMem(dict(cfg, precision=args.precision), None).to(device).eval()
@@ -185,11 +183,6 @@ def run_gpu(args, device, rank, world):
     def one_step(i):
         if host_t is None:
             prob = core.step(frame(i), None, None)
-            if os.environ.get('XMEM_BENCH_HINT_LATE'):
-                out = [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
-                if i % KB == 0:
-                    hint(i + KB)
-                return out
             if i % KB == 0:                          # first frame of its batch consumed: hint the next batch under it
                 hint(i + KB)
             return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]

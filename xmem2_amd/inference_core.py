@@ -7,7 +7,6 @@ reference's conventions (image ``3 x H x W`` float32 normalised, mask ``K x H x 
 import collections
 import functools
 
-import os
 import torch
 
 from . import ops
@@ -153,13 +152,7 @@ class InferenceCore:
             image4 = torch.empty((B, H0 + lh_ + uh_, W0 + lw_ + uw_, 4), dtype=torch.float32, device=net.device)
             packed = [self._pack(d, out=image4[i:i + 1]) for i, d in enumerate(devs)]     # straight into the batched buffer
             pad = self.pad
-            if os.environ.get('XMEM_PREFETCH_EAGER'):                # experiment: the batched pass as eager launches
-                with ops.precision(net._call_precision or net.precision):
-                    ops._ws_suffix = f'@key{gid}@{id(net):x}'
-                    outs = net._encode_key_eager(image4, True, True, False, True)
-                    ops._ws_suffix = ''
-            else:
-                outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=True, slot=gid, inline_skips=True)
+            outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=True, slot=gid, inline_skips=True)
             ev = torch.cuda.Event()
             ev.record(self._side)
         if saved_pad is not None:
