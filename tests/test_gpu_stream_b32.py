@@ -1,0 +1,133 @@
+"""In-stream parity of the headline configuration (BASELINE configs[1]: 480p, 1 object, 32 memory frames) against the
+oracle's RefCore, frame by frame, THROUGH the pipeline that serves the bench line: 32 permanent frames, batched
+`prefetch_keys` hints, every match_memory after the first hinted by the previous frame's top-k (fp16 filter + exact
+refine), hints re-based across a growing temporary store, a long-term consolidation (sieve + prototypes: the segment
+layout [long | temporary | permanent] changes between two hinted calls) and one hard scene cut (the hint of the frame
+before the cut is useless: lists overflow, tighten + second pass).  north_star's tolerance: mask IoU >= 0.999, argmax
+identical wherever the oracle's own top-2 margin is clear.
+
+Second test: clear_memory(keep_permanent=True) (inference_core.py:28-38 -> memory_manager.py:392-425) followed by more
+frames, against the oracle doing the same."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref_net):
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    hw, P, steps, cut = (480, 854), 32, 14, 6
+    # mem_every=4, T_max=2, T_min=1: memory frames at steps 4, 8, 12; the second one fills the temporary store
+    # (2 frames) -> compress_features: 1 frame of candidates -> 128 prototypes, 1 frame stays
+    cfg = base_config(mem_every=4, max_mid_term_frames=2, min_mid_term_frames=1, num_prototypes=128)
+    frames = T(synthetic_frames(P + cut, *hw)); masks = T(synthetic_masks(P + cut, 1, *hw))
+    other = T(synthetic_frames(steps - cut, *hw, seed=777))                    # another scene altogether
+    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
+    for c in (core, ref):
+        c.set_all_labels([1])
+    for j in range(P):
+        core.put_to_permanent_memory(frames[j].cuda(), masks[j].cuda())
+        ref.put_to_permanent_memory(frames[j], masks[j])
+    n_hw = (480 // 16) * (864 // 16)
+    assert core.memory.permanent_work_mem.size == ref.memory.permanent_work_mem.size == P * n_hw == 51840
+    clip = [frames[P + i] for i in range(cut)] + [other[i] for i in range(steps - cut)]
+    dev = [f.cuda() for f in clip]
+    ious, mism, clear_mism, hinted_calls, saw_lt = [], 0, 0, 0, None
+    calls = []
+    orig = ops.affinity_topk
+
+    def spy(segs, qk, qe, top_k, want_sim=False, hint=None):
+        calls.append((sum(k.shape[0] for k, _ in segs if k is not None), hint is not None))
+        return orig(segs, qk, qe, top_k, want_sim=want_sim, hint=hint)
+
+    ops.affinity_topk = spy
+    try:
+        for i in range(steps):
+            if i % 4 == 0:
+                core.prefetch_keys(dev[i:i + 4])
+            p = core.step(dev[i], None, None, end=(i == steps - 1))
+            q = ref.step(clip[i], None, None, end=(i == steps - 1))
+            a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
+            ious.append(R.compute_array_iou(a, b))
+            mism += int((a != b).sum())
+            top2 = torch.topk(q, 2, dim=0).values
+            clear_mism += int(((a != b) & ((top2[0] - top2[1]).numpy() > 2e-2)).sum())
+            m, rm = core.memory, ref.memory
+            assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == \
+                   (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size), f'step {i}: memory sizes differ'
+            if saw_lt is None and m.long_mem.size > 0:
+                saw_lt = i
+            assert float((p.cpu() - q).abs().mean()) < 1e-3, f'step {i}'
+    finally:
+        ops.affinity_topk = orig
+    n_pix = steps * hw[0] * hw[1]
+    print(f'B32 stream: per-step IoU {["%.5f" % x for x in ious]}; argmax mismatch {mism}/{n_pix} (clear margin: {clear_mism}); '
+          f'consolidation at step {saw_lt}; affinity calls (N, hinted): {calls}')
+    assert len(calls) == steps and all(h for _, h in calls[1:]), 'every call after the first must carry a hint'
+    assert all(n >= 51840 for n, _ in calls), 'the memory never drops below the 32 permanent frames (filter path: >= 256 tiles)'
+    assert saw_lt is not None and saw_lt < steps - 2, 'the clip must contain a consolidation with hinted frames after it'
+    assert max(n for n, _ in calls) > 51840 + n_hw, 'temporary frames and prototypes must have been part of hinted calls'
+    assert min(ious[:cut]) >= 0.999, f'IoU before the cut {min(ious[:cut]):.5f} < 0.999'
+    # after the cut the object is matched against an unrelated scene: the mask is whatever both paths make of it - they must
+    # still agree (identical argmax at a clear margin, few flips overall)
+    assert clear_mism == 0, f'{clear_mism} argmax differences where the oracle\'s top-2 margin exceeds 2e-2'
+    assert mism / n_pix < 1e-4, f'argmax mismatch {mism}/{n_pix}'
+
+
+@pytest.mark.parametrize('n_obj', [1, 2])
+def test_clear_memory_keep_permanent_vs_oracle(hip_net, ref_net, n_obj):
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd import ops
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    hw, t = (128, 176), 14
+    cfg = base_config(mem_every=2, max_mid_term_frames=3, min_mid_term_frames=1, num_prototypes=24)
+    frames = T(synthetic_frames(t, *hw)); masks = T(synthetic_masks(t, n_obj, *hw))
+    labels = list(range(1, n_obj + 1))
+    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
+    for c in (core, ref):
+        c.set_all_labels(labels)
+    for j, ti in ((0, 0), (1, 5)):
+        core.put_to_permanent_memory(frames[j].cuda(), masks[j].cuda(), ti=ti)
+        ref.put_to_permanent_memory(frames[j], masks[j], ti=ti)
+
+    def both(i, end=False):
+        p = core.step(frames[i].cuda(), None, None, end=end)
+        q = ref.step(frames[i], None, None, end=end)
+        a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
+        m, rm = core.memory, ref.memory
+        assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == \
+               (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size), f'frame {i}: memory sizes differ'
+        assert m.temporary_work_mem.num_groups == rm.temporary_work_mem.num_groups
+        assert float((p.cpu() - q).abs().mean()) < 5e-4, f'frame {i}'
+        assert float((a != b).mean()) < 1e-3, f'frame {i}'
+        hd = (m.get_hidden().permute(0, 3, 1, 2).cpu() - rm.get_hidden()[0]).abs()
+        assert float(hd.max()) < 5e-3, f'frame {i}: hidden state differs by {float(hd.max()):.2e}'
+        return p
+
+    for i in range(2, 9):                                     # temporary frames, a consolidation, a hidden state that has moved
+        both(i)
+    assert core.memory.temporary_work_mem.size > 0 and core.memory.long_mem.size > 0
+    h_before = core.memory.get_hidden().clone()
+    core.clear_memory(keep_permanent=True); ref.clear_memory(keep_permanent=True)
+    m, rm = core.memory, ref.memory
+    assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == \
+           (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size) == (0, 2 * 8 * 11, 0)
+    assert core.permanent_memory_frames == ref.permanent_memory_frames == [0, 5]
+    assert (core.curr_ti, core.last_mem_ti) == (ref.curr_ti, ref.last_mem_ti) == (-1, 0)
+    assert float(m.get_hidden().abs().max()) == 0.0 and float(rm.get_hidden().abs().max()) == 0.0   # fresh hidden state
+    assert float(h_before.abs().max()) > 0.0
+    for i in range(9, t):                                     # five more frames on the kept permanent memory
+        both(i, end=(i == t - 1))
+    # the permanent store is still editable after the reset (replace at a kept frame id)
+    assert core.put_to_permanent_memory(frames[3].cuda(), masks[3].cuda(), ti=5) is True
+    assert ref.put_to_permanent_memory(frames[3], masks[3], ti=5) is True
+    core.clear_memory(); ref.clear_memory()
+    assert core.memory.permanent_work_mem.size == ref.memory.permanent_work_mem.size == 0

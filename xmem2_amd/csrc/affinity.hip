@@ -825,10 +825,16 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
             const int pos = e < p.hint_k ? e : (e - p.hint_k) - (li - 1) * nbk;
             int o = p.hint_idx[(size_t)nq[li] * p.hint_k + pos];
             // re-base from the old segment layout to today's
-            int sgi = 0, ob = 0;
+            // (prefix sums: the old slot is the LAST one whose first element is <= o.  Testing o against ob + old_n[i] with
+            // ob advanced only on a hit sent an index of an early slot into a later, shorter one - a valid but far looser bound)
+            int sgi = 0, ob = 0, cum = 0;
 #pragma unroll
-            for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i)
-                if (i + 1 < p.old_seg && o >= ob + p.old_n[i]) { ob += p.old_n[i]; sgi = i + 1; }
+            for (int i = 0; i + 1 < XMEM_MAX_SEGMENTS; ++i) {
+                if (i + 1 < p.old_seg) {
+                    cum += p.old_n[i];
+                    if (o >= cum) { ob = cum; sgi = i + 1; }
+                }
+            }
             o -= ob;
             {   // per-lane index into kernel-argument arrays: select, do not load (see seg_of_slot)
                 int mapped = p.new_of_old[0];

@@ -6,6 +6,7 @@ reference's conventions (image ``3 x H x W`` float32 normalised, mask ``K x H x 
 """
 import collections
 import functools
+import weakref
 
 import torch
 
@@ -40,7 +41,12 @@ class InferenceCore:
         self._pfq = collections.deque()      # prefetched frames in the order step() will consume them
         self._group_free = {}                # buffer group -> event after which the side stream may overwrite it
         self._group_parity = {}
-        self._uid = id(self)                 # owner token of this core's captured decoder stages (they update ITS hidden state in place)
+        # owner token of this core's captured decoder stages (they update ITS hidden state in place); recycled when the core dies
+        if hasattr(network, 'acquire_owner'):
+            self._uid = network.acquire_owner()
+            weakref.finalize(self, network.release_owner, self._uid)
+        else:
+            self._uid = id(self)
         # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
         if getattr(network, 'device', None) is not None and network.device.type == 'cuda':
             with torch.cuda.device(network.device):

@@ -57,10 +57,23 @@ def visible_gpus():
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
 
 
-def spawn_ranks(argv, world, extra_env=None, check_devices=True, timeout=None):
+def isolated_device_env(r, parent_env):
+    """Environment that shows rank r exactly ONE GPU (the r-th of what the parent sees): HIP_VISIBLE_DEVICES=<id>, LOCAL_RANK=0.
+    A rank then cannot allocate on, or synchronise with, another rank's device by accident (torch's default device 0 IS its
+    own GPU).  XMEM_DEVICE_ORDINAL keeps the node-wide ordinal for CPU pinning and logs."""
+    vis = parent_env.get('HIP_VISIBLE_DEVICES')
+    ids = [v.strip() for v in vis.split(',') if v.strip() != ''] if vis else None
+    dev = ids[r] if ids and r < len(ids) else str(r)
+    return dict(HIP_VISIBLE_DEVICES=dev, LOCAL_RANK='0', XMEM_DEVICE_ORDINAL=dev)
+
+
+def spawn_ranks(argv, world, extra_env=None, check_devices=True, timeout=None, isolate_devices=False, nonce=None):
     """Start `world` copies of `python <argv...>` with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR=127.0.0.1 / MASTER_PORT), one per GPU, and wait for them.  Returns the list of exit codes.
-    Rank r uses device LOCAL_RANK = r of the visible devices (as torch.distributed.run does)."""
+    Rank r uses device LOCAL_RANK = r of the visible devices (as torch.distributed.run does); with `isolate_devices` each
+    rank sees only its own GPU (`isolated_device_env`; used by the video launcher, whose ranks exchange nothing on the
+    device - bench.py keeps every device visible for its RCCL control plane).  Every rank gets the same
+    XMEM_LAUNCH_NONCE so that results of an earlier run in the same output directory are never mistaken for this one's."""
     if world < 1:
         raise ValueError('world must be >= 1')
     if check_devices:
@@ -68,12 +81,15 @@ def spawn_ranks(argv, world, extra_env=None, check_devices=True, timeout=None):
         if n < world:
             raise SystemExit(f'--gpus {world} requested but only {n} MI355X device(s) are visible: refusing to run on fewer')
     port = free_port()
+    nonce = nonce or f'{os.getpid()}-{port}-{time.time_ns()}'
     procs = []
     for r in range(world):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), XMEM_LAUNCH_NONCE=nonce)
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if isolate_devices:
+            env.update(isolated_device_env(r, os.environ))
         if extra_env:
             env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
@@ -88,6 +104,99 @@ def spawn_ranks(argv, world, extra_env=None, check_devices=True, timeout=None):
                     q.kill()
             codes.append(-9)
     return codes
+
+
+# ---- host-side placement of a rank -------------------------------------------------------------------------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.strip().split(','):
+        part = part.strip()
+        if not part:
+            continue
+        if '-' in part:
+            a, b = part.split('-')
+            out += list(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_local_cpus(pci_bus_id, sysfs='/sys/bus/pci/devices'):
+    """CPUs of the NUMA node the GPU hangs off (sysfs local_cpulist of its PCI function), or None when unknown."""
+    if not pci_bus_id:
+        return None
+    for name in (pci_bus_id.lower(), pci_bus_id.upper()):
+        try:
+            with open(os.path.join(sysfs, name, 'local_cpulist')) as f:
+                cpus = parse_cpulist(f.read())
+            return cpus or None
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def rank_cpu_set(allowed, local_cpus, local_rank, local_world, share_with=None):
+    """The CPUs a rank should run on: the GPU-local CPUs (intersected with what the process may use) split evenly among
+    the `share_with` ranks whose GPUs sit on the same node (index `local_rank` among them), or - when the topology is
+    unknown - an even slice of the allowed set.  Never empty; deterministic."""
+    allowed = sorted(allowed)
+    base = sorted(set(allowed) & set(local_cpus)) if local_cpus else []
+    if base:
+        peers, me = (share_with if share_with else (1, 0))
+    else:
+        base, peers, me = allowed, max(1, local_world), local_rank
+    per = max(1, len(base) // max(1, peers))
+    mine = base[me * per:(me + 1) * per] if me < peers else []
+    return mine or base
+
+
+def pin_rank(local_rank=None, local_world=None, max_threads=8, device_index=None, verbose=False):
+    """One process per GPU: pin this rank to the CPU cores next to its GPU (sched_setaffinity) and cap torch's intra-op
+    threads (the host side of a stream is launch-bound Python + a few decode / writer threads; 256 default OpenMP threads per
+    rank times 8 ranks oversubscribe the box).  eval.py:160-163 runs one core per video; this is the N-process version.
+    Returns dict(cpus, threads, numa_known).  No-op on platforms without sched_setaffinity."""
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))) if local_world is None else local_world
+    # index of this rank among the node's ranks (LOCAL_RANK is 0 for every rank when each sees only its own device)
+    isolated = 'XMEM_DEVICE_ORDINAL' in os.environ
+    slot = (int(os.environ.get('RANK', '0')) % max(1, local_world)) if isolated else local_rank
+    info = dict(cpus=None, threads=None, numa_known=False)
+    import torch
+    if hasattr(os, 'sched_getaffinity') and local_world > 1:
+        allowed = os.sched_getaffinity(0)
+        local, share = None, None
+        try:
+            if torch.cuda.is_available():
+                n = torch.cuda.device_count()
+                ids = [getattr(torch.cuda.get_device_properties(i), 'pci_bus_id', None) for i in range(n)]
+                fmt = lambda p, i: p if isinstance(p, str) else (
+                    '%04x:%02x:%02x.0' % (getattr(torch.cuda.get_device_properties(i), 'pci_domain_id', 0), p,
+                                          getattr(torch.cuda.get_device_properties(i), 'pci_device_id', 0)) if p is not None else None)
+                di = device_index if device_index is not None else (local_rank if n > local_rank else 0)
+                local = gpu_local_cpus(fmt(ids[di], di))
+                if local and n > 1:          # ranks whose GPUs share this NUMA node split its cores
+                    same = [i for i in range(n) if gpu_local_cpus(fmt(ids[i], i)) == local]
+                    share = (len(same), same.index(di))
+                elif local:                  # isolated devices: assume the node's GPUs are spread evenly over the NUMA nodes
+                    nodes = max(1, len(allowed) // max(1, len(local)))
+                    share = (max(1, local_world // nodes), (slot % max(1, local_world // nodes)))
+        except Exception:
+            local = None
+        cpus = rank_cpu_set(allowed, local, slot, local_world, share)
+        try:
+            os.sched_setaffinity(0, cpus)
+            info.update(cpus=len(cpus), numa_known=bool(local))
+        except OSError:
+            pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    threads = max(1, min(max_threads, avail))
+    if local_world > 1:
+        torch.set_num_threads(threads)
+        info['threads'] = threads
+    if verbose:
+        print(f'[launch] rank {os.environ.get("RANK", "0")}: {info}', file=sys.stderr)
+    return info
 
 
 # ---- video lists ---------------------------------------------------------------------------------------------
@@ -139,20 +248,28 @@ def _resolve(spec):
 def worker(args):
     rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    os.makedirs(args.out, exist_ok=True)
+    mine_path = os.path.join(args.out, f'_rank{rank}.json')
+    if os.path.exists(mine_path):                       # a result of an EARLIER run in this directory is not this run's
+        os.remove(mine_path)
     videos = read_video_list(args.videos, args.masks)
+    # every video is checked before any video runs: a missing annotation folder must not cost the work done before it
+    bad = [v['name'] for v in videos if not v['masks'] or not os.path.isdir(v['masks'])]
+    if bad:
+        raise SystemExit(f'no annotation directory for video(s) {bad[:8]}{"..." if len(bad) > 8 else ""} (pass --masks or list it)')
     mine = shard_videos(videos, [v['length'] for v in videos], rank, world)
     if args.device != 'cpu':
         import torch
         if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
             raise SystemExit(f'rank {rank}: device {local} is not visible')
         torch.cuda.set_device(local)
+    if world > 1:
+        pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), max_threads=args.threads_per_rank)
     runner = _resolve(args.runner)
     over = json.loads(args.config) if args.config else {}
     fm = [int(x) for x in args.frames_with_masks.split(',') if x != '']
     results = []
     for v in mine:
-        if not v['masks']:
-            raise SystemExit(f'video {v["name"]}: no annotation directory (pass --masks or list it)')
         t0 = time.perf_counter()
         stats = runner(v['frames'], v['masks'], os.path.join(args.out, v['name']), frames_with_masks=fm,
                        compute_iou=args.compute_iou, print_progress=False, overwrite_config=dict(over))
@@ -162,26 +279,51 @@ def worker(args):
             ious = [float(x) for x in stats['iou'] if x >= 0]
             row['mean_iou'] = sum(ious) / len(ious) if ious else None
         results.append(row)
-    os.makedirs(args.out, exist_ok=True)
-    tmp = os.path.join(args.out, f'_rank{rank}.json.tmp')
+    tmp = mine_path + '.tmp'
     with open(tmp, 'w') as f:
-        json.dump(dict(rank=rank, world=world, videos=results), f)
-    os.replace(tmp, os.path.join(args.out, f'_rank{rank}.json'))
+        json.dump(dict(rank=rank, world=world, nonce=run_nonce(), videos=results), f)
+    os.replace(tmp, mine_path)
     return 0
 
 
-def merge(out_dir, world, wall):
+def run_nonce():
+    """Identifies ONE launch across its ranks: set by spawn_ranks; under torch.distributed.run every local rank has the
+    same agent process as parent and the same rendezvous port."""
+    return os.environ.get('XMEM_LAUNCH_NONCE') or \
+        f'{os.getppid()}-{os.environ.get("MASTER_PORT", "")}-{os.environ.get("TORCHELASTIC_RUN_ID", "")}'
+
+
+def rank_result(out_dir, r, nonce=None):
+    """The per-rank result of THIS launch (matching nonce), or None (absent, unreadable, or left by an earlier run)."""
+    p = os.path.join(out_dir, f'_rank{r}.json')
+    try:
+        with open(p) as f:
+            j = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if nonce is not None and j.get('nonce') != nonce:
+        return None
+    return j
+
+
+def merge(out_dir, world, wall, nonce=None):
     videos, missing = [], []
     for r in range(world):
-        p = os.path.join(out_dir, f'_rank{r}.json')
-        if not os.path.exists(p):
+        j = rank_result(out_dir, r, nonce)
+        if j is None:
             missing.append(r)
             continue
-        with open(p) as f:
-            videos += json.load(f)['videos']
+        videos += j['videos']
     frames = sum(v['frames'] for v in videos)
+    per_rank = {}
+    for v in videos:
+        d = per_rank.setdefault(v['rank'], dict(frames=0, seconds=0.0, videos=0))
+        d['frames'] += v['frames']; d['seconds'] += v['seconds']; d['videos'] += 1
+    busy = [d['seconds'] for d in per_rank.values()]
     summary = dict(n_gpus=world, videos=sorted(videos, key=lambda v: v['name']), total_frames=frames, wall_seconds=wall,
-                   aggregate_fps=frames / wall if wall > 0 else None, ranks_missing=missing)
+                   aggregate_fps=frames / wall if wall > 0 else None, ranks_missing=missing,
+                   per_rank={str(k): v for k, v in sorted(per_rank.items())},
+                   slowest_rank_seconds=max(busy) if busy else None, fastest_rank_seconds=min(busy) if busy else None)
     with open(os.path.join(out_dir, 'summary.json'), 'w') as f:
         json.dump(summary, f, indent=1)
     return summary
@@ -199,6 +341,8 @@ def main(argv=None):
     ap.add_argument('--runner', default='xmem2_amd.run_on_video:run_on_video', help='module:function with run_on_video\'s signature')
     ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'], help='cpu only for launcher tests with a stub runner')
     ap.add_argument('--merge-timeout', type=float, default=86400.0, help='under torchrun: how long rank 0 waits for the other ranks\' results')
+    ap.add_argument('--threads-per-rank', type=int, default=8, help='torch intra-op threads per rank (ranks are pinned to the cores next to their GPU)')
+    ap.add_argument('--no-isolate', action='store_true', help='keep every GPU visible in every rank (default: a rank sees only its own)')
     ap.add_argument('--as-worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     under_torchrun = (not args.as_worker) and int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'RANK' in os.environ
@@ -209,9 +353,10 @@ def main(argv=None):
         rc = worker(args)
         if under_torchrun and int(os.environ['RANK']) == 0:        # launched by torch.distributed.run: rank 0 merges
             deadline = time.time() + args.merge_timeout
-            while time.time() < deadline and not all(os.path.exists(os.path.join(args.out, f'_rank{r}.json')) for r in range(args.gpus)):
+            nonce = run_nonce()
+            while time.time() < deadline and not all(rank_result(args.out, r, nonce) is not None for r in range(args.gpus)):
                 time.sleep(0.5)
-            merge(args.out, args.gpus, time.perf_counter() - t0)
+            merge(args.out, args.gpus, time.perf_counter() - t0, nonce)
         return rc
     os.makedirs(args.out, exist_ok=True)
     for r in range(args.gpus):
@@ -220,12 +365,15 @@ def main(argv=None):
             os.remove(p)
     t0 = time.perf_counter()
     child = ['-m', 'xmem2_amd.launch', '--as-worker'] + [a for a in (argv if argv is not None else sys.argv[1:])]
-    codes = spawn_ranks(child, args.gpus, check_devices=(args.device != 'cpu'),
+    nonce = f'{os.getpid()}-{time.time_ns()}'
+    codes = spawn_ranks(child, args.gpus, check_devices=(args.device != 'cpu'), nonce=nonce,
+                        isolate_devices=(args.device != 'cpu' and not args.no_isolate),
                         extra_env={'PYTHONPATH': os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] +
                                                                  [p for p in os.environ.get('PYTHONPATH', '').split(os.pathsep) if p])})
     wall = time.perf_counter() - t0
-    summary = merge(args.out, args.gpus, wall)
-    print(json.dumps({k: summary[k] for k in ('n_gpus', 'total_frames', 'wall_seconds', 'aggregate_fps', 'ranks_missing')}))
+    summary = merge(args.out, args.gpus, wall, nonce)
+    print(json.dumps({k: summary[k] for k in ('n_gpus', 'total_frames', 'wall_seconds', 'aggregate_fps', 'ranks_missing',
+                                              'slowest_rank_seconds', 'fastest_rank_seconds')}))
     if any(c != 0 for c in codes) or summary['ranks_missing']:
         raise SystemExit(f'rank exit codes {codes}, missing results from ranks {summary["ranks_missing"]}')
     return 0

@@ -10,8 +10,10 @@ loads unchanged.  Internally nothing is an nn.Module: at load time every convolu
 Public methods take / return NCHW-shaped tensors like the reference (zero-copy permuted views of the
 NHWC buffers); the ``*_nhwc`` methods are the hot path used by ``InferenceCore``.
 """
+import collections
 import os
 import warnings
+import weakref
 
 import torch
 
@@ -40,8 +42,9 @@ class XMem:
         self.precision = config.get('precision', os.environ.get('XMEM_PRECISION', 'fp32'))
         if self.precision not in ('fp32', 'fp16'):
             raise ValueError(f"config['precision'] must be 'fp32' or 'fp16', got {self.precision!r}")
-        self._stages = {}
+        self._stages = collections.OrderedDict()     # captured stages, least recently replayed first
         self._zeros = {}
+        self._owner_free, self._owner_next = [], 0   # owner tokens of the cores driving this network (see acquire_owner)
         self._call_precision = None      # per-call override (InferenceCore preloads permanent memory in fp32)
         self.max_stages = int(os.environ.get('XMEM_MAX_STAGES', '160'))   # captured HIP-graph stages kept before the cache is dropped
         # the decoder's skip convolutions depend only on f8 / f4: inside the captured key-encoder graph they run on a
@@ -50,6 +53,9 @@ class XMem:
         self.overlap_skips = os.environ.get('XMEM_OVERLAP', '0') != '0'
         self.share_x = os.environ.get('XMEM_SHARE_X', '1') != '0'     # several objects: convolve the shared f16 half of the fusers once
         self._side = None
+        # scratch of the side-stream key-encoder stages is scoped to this instance and released with it
+        self._scope = ops.new_scope()
+        weakref.finalize(self, ops.release_scope, self._scope)
         weights = self.init_hyperparameters(config, model_path, map_location)
         if weights is not None:
             self.load_weights(weights, init_as_zero_if_needed=True)
@@ -255,18 +261,46 @@ class XMem:
                 with torch.cuda.graph(graph):
                     static_out = fn(*static_in)
             st = (graph, static_in, static_out)
-            if len(self._stages) >= self.max_stages:
-                # bound the cache: every resolution / object count / slot adds graphs with private pools.  Stages alias each
-                # other's static buffers (the decoder reads the key encoder's outputs in place), so the whole cache goes
-                # together; everything is re-captured on demand.
-                self._stages.clear()
+            while len(self._stages) >= self.max_stages:
+                self._evict_lru()
             self._stages[full_key] = st
+        else:
+            self._stages.move_to_end(full_key)
         graph, static_in, static_out = st
         for dst, src in zip(static_in, inputs):
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         graph.replay()
         return static_out
+
+    def _evict_lru(self):
+        """Bound the cache (every resolution / object count / slot / owner adds graphs with private pools): drop the least
+        recently replayed stage.  Decoder and value stages read a key-encoder stage's outputs in place; when a key stage goes,
+        the stages aliasing its buffers go with it (they would otherwise pay a copy per frame into buffers nobody produces
+        into any more) and are re-captured on demand against the new key stage."""
+        key, st = self._stages.popitem(last=False)
+        if key[0] != 'key':
+            return
+        spans = [(o.data_ptr(), o.data_ptr() + o.numel() * o.element_size()) for o in st[2] if isinstance(o, torch.Tensor)]
+        for o in st[2]:
+            if isinstance(o, tuple):
+                spans += [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in o if isinstance(t, torch.Tensor)]
+        inside = lambda t: isinstance(t, torch.Tensor) and any(a <= t.data_ptr() < b for a, b in spans)
+        for k in [k for k, v in self._stages.items() if k[0] != 'key' and any(inside(t) for t in v[1])]:
+            del self._stages[k]
+
+    def acquire_owner(self):
+        """Owner token of an InferenceCore: its decoder stages advance ITS hidden state in place, so stages are keyed by
+        owner.  Tokens are small integers recycled when a core dies (`release_owner`): the next core (eval.py builds one per
+        video) takes over the dead core's captured stages - its fresh hidden state is copied into the stage's state buffer
+        once and the core then continues on that buffer - instead of re-capturing every decoder graph per video."""
+        if self._owner_free:
+            return self._owner_free.pop()
+        self._owner_next += 1
+        return self._owner_next
+
+    def release_owner(self, token):
+        self._owner_free.append(token)
 
     def _is_stage_output(self, t):
         """True when `t` lives inside a static output buffer of a key-encoder stage (a whole output, or the slice of one
@@ -353,19 +387,16 @@ class XMem:
                        and image4.shape[0] == 1)
         inline = bool(with_skips and inline_skips)      # a prefetched pass also runs the decoder's skip convolutions
         # key-encoder graphs may run on a side stream: never share scratch with the decoder, nor with another network instance
-        ops._ws_suffix = f'@key{slot}@{id(self):x}'
-        try:
+        self._key_ws = f'@key{slot}#{self._scope}#'
+        with ops.ws_scope(self._key_ws):
             out = self._run_stage('key', (need_sk, need_ek, overlap, inline, slot), [image4],
                                   lambda im: self._encode_key_eager(im, need_sk, need_ek, overlap, inline))
-        finally:
-            ops._ws_suffix = ''
         if with_skips:
             return out if (overlap or inline) else tuple(out) + (None,)
         return out[:6]
 
     def _encode_key_eager(self, image4, need_sk, need_ek, overlap=False, inline_skips=False):
         W = self._w
-        self._key_ws = ops._ws_suffix
         x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
         x = ops.maxpool3x3s2(x)
         f4 = self._stage(x, 'key_encoder.res2', 3, self._bottleneck)
@@ -375,17 +406,13 @@ class XMem:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=image4.device)
             self._side.wait_stream(main)                       # fork: f4 is ready
-            ops._ws_suffix = '@side4'
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(self._side), ops.ws_scope(f'@side4#{self._scope}#'):
                 skip4 = ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
-            ops._ws_suffix = self._key_ws
         f8 = self._stage(f4, 'key_encoder.layer2', 4, self._bottleneck)
         if overlap:
             self._side.wait_stream(main)                       # f8 is ready
-            ops._ws_suffix = '@side8'
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(self._side), ops.ws_scope(f'@side8#{self._scope}#'):
                 skip8 = ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
-            ops._ws_suffix = self._key_ws
         f16 = self._stage(f8, 'key_encoder.layer3', 6, self._bottleneck)
         B, h, w, _ = f16.shape
         ld = _pad4(2 * self.key_dim + 1)

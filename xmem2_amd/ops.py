@@ -6,8 +6,10 @@ torch is plumbing only: allocation, streams.  No torch compute op is used on the
 """
 import ctypes as C
 import json
+import contextlib
 import os
 import sys
+import threading
 
 import torch
 
@@ -15,8 +17,39 @@ from . import _lib
 from ._lib import AffinityHint, ConvDesc, KeySegment, ValueSegment, check, load, ptr, stream_ptr
 
 _workspaces = {}
-_retired = []
-_ws_suffix = ''
+_retired = {}                  # key -> outgrown buffers that captured HIP graphs may still point into
+_tls = threading.local()       # .suffix: scratch scope of the calling thread (see ws_scope)
+_scope_free, _scope_next = [], [0]
+
+
+def new_scope():
+    """Small recycled integer naming one owner of scoped scratch (an XMem instance: its side-stream key-encoder stages).
+    `release_scope` drops every workspace of the scope when the owner dies, so a process that builds one network per video
+    (run_on_video, launch.py) does not keep ~100 MB of conv scratch per dead network."""
+    if _scope_free:
+        return _scope_free.pop()
+    _scope_next[0] += 1
+    return _scope_next[0]
+
+
+@contextlib.contextmanager
+def ws_scope(suffix):
+    """Kernels launched inside take their scratch from buffers tagged `suffix` (per host thread, nestable): stages that may
+    run concurrently with the main stream (the side-stream key encoder) never share scratch with it."""
+    prev = getattr(_tls, 'suffix', '')
+    _tls.suffix = suffix
+    try:
+        yield
+    finally:
+        _tls.suffix = prev
+
+
+def release_scope(scope):
+    mark = f'#{scope}#'
+    for d in (_workspaces, _retired):
+        for key in [k for k in d if mark in k[1]]:
+            del d[key]
+    _scope_free.append(scope)
 
 # Optional live kernel timing for bench.py.  RECORD = [] makes conv2d / affinity_topk append a re-launchable
 # closure for every call of one (eager) frame; time_recorded() then times each distinct launch back to back between
@@ -73,14 +106,14 @@ def time_recorded(records, reps=10):
 
 def workspace(nbytes, device, tag='default'):
     """Grow-only scratch buffer per (device, tag + scope suffix); kernels on one stream run in order so reuse is safe.
-    The scope suffix (`_ws_suffix`, set by XMem around its side-stream key-encoder stages, unique per network instance and
-    graph slot) keeps concurrently running streams on separate scratch.  The module is single-threaded by contract (as the
-    reference's InferenceCore): two host threads driving kernels at once are not supported."""
-    key = (str(device), tag + _ws_suffix)      # kernels on a side stream get their own scratch
+    The scope suffix (`ws_scope`, entered by XMem around its side-stream key-encoder stages, unique per network instance and
+    graph slot) keeps concurrently running streams on separate scratch; it is thread-local, so two host threads driving
+    different networks do not see each other's scope."""
+    key = (str(device), tag + getattr(_tls, 'suffix', ''))      # kernels on a side stream get their own scratch
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
-            _retired.append(buf)        # captured HIP graphs may still hold the old pointer: never free it
+            _retired.setdefault(key, []).append(buf)   # captured HIP graphs may still hold the old pointer: kept while the scope lives
         grow = max(int(nbytes), 2 * (buf.numel() if buf is not None else 0), 1 << 20)
         buf = torch.empty(grow, dtype=torch.uint8, device=device)
         _workspaces[key] = buf
@@ -189,8 +222,8 @@ def dump_tuned_plans(path):
     """Write every plan known to this process (shipped + tuned now) - used to refresh conv_plans.json."""
     allp = dict(_load_plans())
     allp.update(_tuned_now)
-    if WINO4:
-        allp['__tuned_with_f4__'] = (1, 0)           # every entry was measured against the F(4x4) candidates too
+    if WINO4 and (os.environ.get('XMEM_RETUNE_ALL') or '__tuned_with_f4__' in allp):
+        allp['__tuned_with_f4__'] = (1, 0)           # EVERY entry was measured against the F(4x4) candidates (full retune only)
     with open(path, 'w') as f:
         json.dump({k: list(v) for k, v in sorted(allp.items())}, f, indent=0)
     return len(allp)
@@ -283,6 +316,11 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         plan = (0, 0)
         if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
             plan = _tune_conv(lib, d, x.device, cw)
+        elif cw.wu is not None and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0):
+            # a shape the shipped table does not know (another resolution / object count): the 3x3 stride-1 layers still take
+            # Winograd with the 64x64 GEMM tile - F(4x4) from 1/8 resolution of 480p up, F(2x2) below - instead of the direct
+            # form (deterministic: same shape -> same plan on every machine)
+            plan = (19, 1) if (WINO4 and Ho * Wo >= WINO4_MIN_PIXELS) else (9, 1)
         _tuned_now[key] = plan
     d.w_winograd4 = None
     if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32' \
@@ -293,6 +331,8 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             cw.wu4 = winograd4_weights(cw.w)
         d.w_winograd4 = cw.wu4.data_ptr()
         plan = (plan[0] + 10, plan[1])
+    elif 17 <= plan[0] <= 22 and not WINO4 and not explicit:
+        plan = (plan[0] - 10, plan[1])               # XMEM_WINO4=0: the same GEMM tile under F(2x2)
     elif 17 <= plan[0] <= 22:
         if cw.wu4 is None and cw.wu is not None:
             cw.wu4 = winograd4_weights(cw.w)
