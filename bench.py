@@ -47,6 +47,14 @@ F16_K = 144                            # contraction length of the fp16 filter (
 CK, CV, TOPK = 64, 512, 30
 BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
 
+PRECISION_LABEL = {'fp32': '',
+                   'fp16': ' [REDUCED-PRECISION MODE fp16: not the headline metric]',
+                   'fp32x': ' [SPLIT-OPERAND EXPERIMENT fp32x: separately reported, not the headline metric]'}
+PRECISION_DTYPE = {'fp32': 'f32',
+                   'fp16': 'f16 Winograd-domain conv operands, f32 accumulate; everything else f32',
+                   'fp32x': 'f32 carried as f16 pairs (hi + lo) in the conv GEMMs: four partial products on the fp16 MFMA, f32 accumulate; '
+                            'tensors, memory readout and everything else f32'}
+
 WORKLOADS = {
     'b32': dict(H=480, W=854, K=1, perm=32, mem_every=10 ** 9, count_usage=False, n_query=32,
                 desc='B32: synthetic 480x854 clip, 1 object, 32 permanent memory frames (N=51840), mem_every=1e9'),
@@ -440,9 +448,10 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='b32', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline at its best thread count')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16'],
-                    help='fp16 = the opt-in reduced-precision mode (Winograd-domain operands in fp16, fp32 accumulation; SURVEY 8f-4): '
-                         'reported under its own metric label, never the headline')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16', 'fp32x'],
+                    help='fp16 = the opt-in reduced-precision mode (Winograd-domain operands in fp16, fp32 accumulation; SURVEY 8f-4); '
+                         'fp32x = the split-operand experiment (every fp32 GEMM operand carried as two halfs, four partial products on the '
+                         'fp16 MFMA, fp32 accumulation: fp32-class results).  Both are reported under their own metric label, never the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefetch', action='store_true', help='do not pipeline the coming frames\' key encoder')
     ap.add_argument('--key-batch', type=int, default=4, help='frames per batched key-encoder hint (prefetch_keys)')
@@ -517,11 +526,10 @@ def main():
         aff_gf = aff['flop'] / nf / 1e9 if aff else alg['similarity']
         aff_tflops = (aff_gf / aff_ms) if aff_ms else None                     # GF / ms = TF/s
         line = {
-            'metric': (BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})') +
-                      ('' if args.precision == 'fp32' else ' [REDUCED-PRECISION MODE fp16: not the headline metric]'),
+            'metric': (BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})') + PRECISION_LABEL[args.precision],
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'f16 Winograd-domain conv operands, f32 accumulate; everything else f32',
+            'vs_baseline': None, 'dtype': PRECISION_DTYPE[args.precision],
             'data': 'synthetic',
             'config': {'workload': wl['desc'] + '; step()+argmax+uint8 mask to host per frame, conditioned synthetic weights',
                        'workload_key': args.workload, 'replica_streams': world, 'top_k': TOPK,

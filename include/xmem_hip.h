@@ -79,6 +79,17 @@ typedef struct {
     const void* w_winograd_f16; /* optional [16][Cout][Cin] IEEE half: the same G g G^T rounded to fp16 (plan_tile 16 only) */
     const float* w_winograd4;   /* optional [36][Cout][Cin]: G g G^T of Winograd F(4x4,3x3) (plan_tile 17..22 = the GEMM tiles of
                                    plans 7..12 inside the F(4x4) path; fp32, ~9e-6 of the output scale vs a fp64 convolution) */
+    /* SPLIT-OPERAND ARITHMETIC (opt-in mode 'fp32x', never the default): arith = 1 and w_split != NULL run every GEMM of the
+     * call on v_mfma_f32_32x32x16_f16 with each fp32 operand carried as two halfs (x = hi + lo, relative representation error
+     * <= 2^-21; the four partial products are accumulated in fp32).  The split weights have the SHAPE of their fp32
+     * counterparts ([Cout][KH][KW][Cin], [16][Cout][Cin], [36][Cout][Cin]) with every group of four input channels stored as
+     * eight halfs [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (16 bytes, like the four floats), pre-multiplied by a power of two
+     * 2^s that the caller folds into `scale` (scale * 2^-s: exact).  Activations stay fp32 in memory; the Winograd-domain
+     * intermediate V is written in the same group format.  Same call sites as above; arith = 0 ignores these fields. */
+    int arith;
+    const void* w_split;
+    const void* w_winograd_split;
+    const void* w_winograd4_split;
 } xmem_conv_desc;
 
 size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);

@@ -273,3 +273,33 @@ def test_affinity_workspace_layout_is_consistent():
     assert sizes[0] < sizes[1] < sizes[2]
     assert lib.xmem_affinity_topk_workspace_bytes(0, 1620, 30) == 0
     assert lib.xmem_affinity_debug_offsets(0, 1620, None, None, None) != 0
+
+
+def test_library_has_no_packed_fp32_valu_instructions(tmp_path):
+    """Build rule (xmem2_amd/build.py DEVICE_FLAGS): no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in any kernel - on MI355X
+    they returned wrong values next to a concurrently running v_mfma_f32_32x32x16_f16 kernel (measured, round 3).  Every
+    object of the library is unbundled and disassembled; the device code must contain MFMA instructions (so the
+    disassembly really is the gfx950 code) and none of the packed-f32 arithmetic ones."""
+    import re
+    import shutil
+    import subprocess
+    from xmem2_amd import build as B
+    llvm = '/opt/rocm/lib/llvm/bin'
+    tools = [os.path.join(llvm, t) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-objdump')]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip('ROCm LLVM binutils not installed')
+    B.build(force=False, verbose=False)
+    total_mfma = 0
+    for src in B.SOURCES:
+        obj = os.path.join(B.CSRC, src.replace('.hip', '.o'))
+        assert os.path.exists(obj), obj
+        fat, co = str(tmp_path / 'fat.bin'), str(tmp_path / 'dev.co')
+        subprocess.run([tools[0], '-O', 'binary', '--only-section=.hip_fatbin', obj, fat], check=True)
+        subprocess.run([tools[1], '--unbundle', '--type=o', f'--input={fat}', f'--targets=hipv4-amdgcn-amd-amdhsa--{B.ARCH}',
+                        f'--output={co}'], check=True)
+        asm = subprocess.run([tools[2], '-d', co], check=True, capture_output=True, text=True).stdout
+        assert 's_endpgm' in asm, f'{src}: no device code found'
+        packed = re.findall(r'\bv_pk_(?:fma|mul|add)_f32\b', asm)
+        assert not packed, f'{src}: {len(packed)} packed-f32 VALU instructions in the device code (build without -packed-fp32-ops?)'
+        total_mfma += len(re.findall(r'\bv_mfma_', asm))
+    assert total_mfma > 1000

@@ -13,6 +13,15 @@ SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'affinity_filter.
 HEADERS = ['common.hpp', 'affinity_common.hpp']
 LIB = os.path.join(CSRC, 'libxmem_hip.so')
 ARCH = 'gfx950'
+EXTRA_FLAGS = {}          # per-source compiler flags
+# NO PACKED-FP32 VALU INSTRUCTIONS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel of this library.  Measured on MI355X
+# (round 3, tools/probes/victim_decoder_probe.py, hog_probe.py): an elementwise kernel built with them returned wrong values
+# in ~1e-4 of its elements (one 32-bit half of a packed result) WHILE a kernel issuing v_mfma_f32_32x32x16_f16 ran on another
+# stream - the memory-readout filter and the split-operand GEMMs do exactly that next to the side-stream key encoder.  With
+# the subtarget feature turned off the same runs are bit-identical to the solo runs.  (The flag reaches the host compilation
+# too, which prints an 'ignoring feature' note - filtered below.)
+DEVICE_FLAGS = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)"
 
 
 def _hipcc():
@@ -40,6 +49,7 @@ def source_digest():
             h.update(fh.read())
     with open(os.path.join(os.path.dirname(CSRC), '..', 'include', 'xmem_hip.h'), 'rb') as fh:
         h.update(fh.read())
+    h.update(' '.join(DEVICE_FLAGS).encode())
     return h.hexdigest()[:16]
 
 
@@ -52,8 +62,8 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c',
-               os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + DEVICE_FLAGS + EXTRA_FLAGS.get(src, []) + \
+              os.environ.get('XMEM_HIPCC_FLAGS', '').split() + ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -61,6 +71,7 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f'hipcc failed on {src}:\n{out}')
+        out = '\n'.join(l for l in out.splitlines() if _NOISE not in l and l.strip())
         if verbose and out.strip():
             print(out)
     cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs

@@ -32,13 +32,37 @@ struct ConvArgs {
     int raw;                                   // 1: store the bare accumulator (Winograd-domain GEMM)
     int res_mod;                               // > 0: residual is one image broadcast over the batch (pixel index mod Ho*Wo)
     long in_gstride, w_gstride, out_gstride;   // blockIdx.y = group (the 16 Winograd tile positions), floats
+    int a_presplit;                            // SPLIT kernels: the A operand already holds [hi4|lo4] groups (Winograd-domain V)
 };
+
+// ---- SPLIT-OPERAND arithmetic (opt-in mode 'fp32x', never the default) ------------------------------------------------
+// An fp32 value x is carried as two halfs, x = hi + lo (+ O(2^-21 |x|)): hi = x rounded toward zero to fp16 (saturating:
+// finite values never become inf), lo = fp16(x - hi).  Four channels travel as ONE 16-byte group [hi0 hi1 hi2 hi3 | lo0 lo1
+// lo2 lo3] - the same bytes as the four floats they replace, so tensor shapes, pixel strides, LDS layout and every loader of
+// this file are unchanged.  As an operand of v_mfma_f32_32x32x16_f16 a group fills the 8 k-slots of a lane, and with B the
+// same layout   mfma(A, B) = sum hi_a hi_b + lo_a lo_b,   mfma(A, swap halves of B) = sum hi_a lo_b + lo_a hi_b :
+// two fp16 MFMAs (2 x 32 cycles) give all four partial products of 8 channels, where the fp32 pipe spends 4 x 64 cycles.
+// Products of halfs are exact in the fp32 accumulator; what is lost is the representation error of the two operands.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 split_pack(const f32x4 v) {
+    const fp16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    h16x8 o;
+    o[0] = (_Float16)h01.x; o[1] = (_Float16)h01.y; o[2] = (_Float16)h23.x; o[3] = (_Float16)h23.y;
+    // the residual of a saturated hi is clamped as well: |x| beyond 131008 saturates instead of turning into inf - inf
+    o[4] = (_Float16)__builtin_amdgcn_fmed3f(v.x - (float)h01.x, -65504.f, 65504.f);
+    o[5] = (_Float16)__builtin_amdgcn_fmed3f(v.y - (float)h01.y, -65504.f, 65504.f);
+    o[6] = (_Float16)__builtin_amdgcn_fmed3f(v.z - (float)h23.x, -65504.f, 65504.f);
+    o[7] = (_Float16)__builtin_amdgcn_fmed3f(v.w - (float)h23.y, -65504.f, 65504.f);
+    return __builtin_bit_cast(f32x4, o);
+}
 
 // ONE: 1x1 / pad 0 (any stride) with Cin % BK == 0 (the pointwise layers and the 16 Winograd-domain GEMMs): operand rows are
 // plain matrix rows, so each thread keeps loop-invariant 32-bit byte offsets and the K loop only advances a uniform base -
 // no per-tile index arithmetic, bounds tests or exec-masked branches around the loads (rows past M / Cout are clamped:
 // their products are never stored).  The address VALU work of the general loader was comparable to the MFMA issue time.
-template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false>
+template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WN = BN / (32 * TN);
     constexpr int WM = BM / (32 * TM);
@@ -160,6 +184,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
             }
         }
+        if (SPLIT && !p.a_presplit) {          // fp32 activations become [hi4|lo4] groups on their way into LDS
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = split_pack(ra[i]);
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + RPP * i) * LDK + c4 * 4]) = ra[i];
 #pragma unroll
@@ -204,13 +232,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + (kk + 1) * 8);
             }
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch above this k-group's MFMAs
+            if (SPLIT) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int j = 0; j < TN; ++j) {
+                    const h16x8 b = __builtin_bit_cast(h16x8, bf[cur][j]);
+                    const h16x8 bs = __builtin_shufflevector(b, b, 4, 5, 6, 7, 0, 1, 2, 3);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) {
+                        const h16x8 a = __builtin_bit_cast(h16x8, af[cur][i]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bs, acc[i][j], 0, 0, 0);
+                    }
+                }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+            }
         }
         if (has_next) store_tile(buf ^ 1);
         __syncthreads();
@@ -314,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
 // MFMA kernel (blockIdx.y = tile position), between two HBM-bound transform kernels.  All fp32.
 // ----------------------------------------------------------------------------------------------
 __global__ void wino_input_kernel(const float* __restrict__ in, int ldin, int B, int H, int W, int C, int th, int tw,
-                                  int relu_in, float* __restrict__ V) {
+                                  int relu_in, float* __restrict__ V, int split) {
     const int C4 = C >> 2;
     const size_t P = (size_t)B * th * tw;
     const size_t total = P * C4;
@@ -349,7 +391,8 @@ __global__ void wino_input_kernel(const float* __restrict__ in, int ldin, int B,
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {          // (B^T d) B (columns)
-            const f32x4 v0 = u[i][0] - u[i][2], v1 = u[i][1] + u[i][2], v2 = u[i][2] - u[i][1], v3 = u[i][1] - u[i][3];
+            f32x4 v0 = u[i][0] - u[i][2], v1 = u[i][1] + u[i][2], v2 = u[i][2] - u[i][1], v3 = u[i][1] - u[i][3];
+            if (split) { v0 = split_pack(v0); v1 = split_pack(v1); v2 = split_pack(v2); v3 = split_pack(v3); }   // 'fp32x' mode
             float* o = V + ((size_t)(i * 4) * P + t) * C + c4 * 4;
             *reinterpret_cast<f32x4*>(o) = v0;
             *reinterpret_cast<f32x4*>(o + P * C) = v1;
@@ -589,7 +632,7 @@ __device__ __forceinline__ void wino4_at(const f32x4* m, f32x4* s) {      // s =
 }
 
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ in, int ldin, int B, int H, int W, int C, int th, int tw,
-                                                          int relu_in, float* __restrict__ V) {
+                                                          int relu_in, float* __restrict__ V, int split) {
     const int C4 = C >> 2;
     const size_t P = (size_t)B * th * tw;
     const size_t total = P * C4;
@@ -628,7 +671,8 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
             f32x4 tr[6];
             wino4_bt(d[i], tr);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(V + ((size_t)(i * 6 + j) * P + t) * C + c4 * 4) = tr[j];
+            for (int j = 0; j < 6; ++j)
+                *reinterpret_cast<f32x4*>(V + ((size_t)(i * 6 + j) * P + t) * C + c4 * 4) = split ? split_pack(tr[j]) : tr[j];
         }
     }
 }
@@ -844,7 +888,7 @@ __global__ __launch_bounds__(256) void wino_gemm_f16_kernel(WinoF16Args p) {
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; bool wino4; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; bool wino4; bool split; };
 
 inline bool wino_ok(const xmem_conv_desc* d) {
     return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
@@ -878,15 +922,19 @@ Plan make_plan(const xmem_conv_desc* d) {
     pl.fused = 0;
     pl.f16 = false;
     pl.wino4 = false;
-    if (d->Cout == 1) { pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
+    // split-operand arithmetic ('fp32x', opt-in): every GEMM-shaped path; the Cout = 1 GEMV stays fp32 (it is HBM-bound)
+    pl.split = d->arith == 1 && d->w_split != nullptr;
+    if (d->Cout == 1) { pl.split = false; pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
     auto tiles = [&](int bm, int bn) { return (long)cdiv(M, bm) * cdiv(d->Cout, bn); };
     if (d->plan_tile > 0) {
         static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
         int t = d->plan_tile;
         if (t >= 17) {                     // F(4x4, 3x3) with the GEMM tile of plan t - 10; F(2x2) when its operand is absent
-            if (wino_ok(d) && d->w_winograd4) pl.wino4 = true;
+            if (wino_ok(d) && (pl.split ? d->w_winograd4_split : (const void*)d->w_winograd4)) pl.wino4 = true;
             t -= 10;
         }
+        if (pl.split && t == 16) t = 9;    // the fp16-storage mode and the split mode exclude each other
+        if (pl.split && t > 12) t = (t == 13) ? 8 : 9;   // fused GEMM + output transform has no split variant: separate transform
         if (t == 16) {                     // reduced-precision Winograd (opt-in); falls back to the fp32 Winograd tile 64x64
             if (wino_ok(d) && d->w_winograd_f16 && d->Cin % 64 == 0) {
                 pl.wino = true; pl.f16 = true; pl.bm = 0; pl.bn = 0; pl.nk = d->Cin / 64; pl.splitk = 1; pl.kt_per_split = pl.nk;
@@ -898,7 +946,7 @@ Plan make_plan(const xmem_conv_desc* d) {
             if (wino_ok(d)) { pl.wino = true; pl.fused = t - 12; }
             t = (t == 13) ? 2 : 3;         // fall back to a direct tile when Winograd is not applicable
         }
-        if (t > 6 && wino_ok(d)) { pl.wino = true; }
+        if (t > 6 && wino_ok(d) && (!pl.split || d->w_winograd_split)) { pl.wino = true; }
         if (t > 6) t -= 6;
         pl.bm = cfg[t - 1][0]; pl.bn = cfg[t - 1][1]; pl.bk = cfg[t - 1][2];
         if (pl.wino) {           // the GEMM runs per tile position: M = tiles, K = Cin, no split-K
@@ -940,10 +988,13 @@ static bool conv_is_one(const ConvArgs& a) {
 }
 
 template <int BM, int BN, int TM, int TN, int BK, bool G>
-int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1) {
+int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = false) {
     const size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false>;
-    if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true>;
+    auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false, false>;
+    if (split) {
+        kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false, true>;
+        if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true, true>;
+    } else if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true, false>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
@@ -955,9 +1006,9 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1) {
 
 template <int BK, bool G>
 int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s, int groups = 1) {
-    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s, groups);
-    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s, groups);
-    return launch_cfg<64, 64, 1, 1, BK, G>(a, s, groups);
+    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s, groups, pl.split);
+    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s, groups, pl.split);
+    return launch_cfg<64, 64, 1, 1, BK, G>(a, s, groups, pl.split);
 }
 
 }  // namespace
@@ -981,7 +1032,9 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     Plan pl = make_plan(d);
     int Ho, Wo; out_dims(d, Ho, Wo);
     ConvArgs a;
-    a.in = d->in; a.w = d->w; a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.out = d->out;
+    a.in = d->in; a.w = pl.split ? reinterpret_cast<const float*>(d->w_split) : d->w;
+    a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.out = d->out;
+    a.a_presplit = 0;
     a.partial = reinterpret_cast<float*>(workspace);
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldin = d->ldin;
     a.Ho = Ho; a.Wo = Wo; a.Cout = d->Cout; a.ldout = d->ldout; a.ldres = d->ldres;
@@ -1003,9 +1056,10 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         size_t tot = P * (d->Cin / 4);
         int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(wino4_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
-                           d->relu_in, V);
+                           d->relu_in, V, pl.split ? 1 : 0);
         ConvArgs g = a;
-        g.in = V; g.w = d->w_winograd4; g.out = Mt; g.res = nullptr; g.partial = nullptr;
+        g.in = V; g.w = pl.split ? reinterpret_cast<const float*>(d->w_winograd4_split) : d->w_winograd4;
+        g.a_presplit = 1; g.out = Mt; g.res = nullptr; g.partial = nullptr;
         g.B = 1; g.H = 1; g.W = (int)P; g.ldin = d->Cin; g.Ho = 1; g.Wo = (int)P; g.ldout = d->Cout; g.ldres = 0;
         g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.K = d->Cin; g.M = (int)P; g.HoWo = (int)P;
         g.relu_in = 0; g.relu_out = 0; g.nk = pl.nk; g.splitk = 1; g.kt_per_split = pl.nk;
@@ -1065,7 +1119,7 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         size_t tot = P * (d->Cin / 4);
         int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
-                           d->relu_in, V);
+                           d->relu_in, V, pl.split ? 1 : 0);
         if (pl.fused) {
             WinoArgs wa;
             wa.V = V; wa.U = d->w_winograd; wa.scale = d->scale; wa.shift = d->shift; wa.res = d->res; wa.out = d->out;
@@ -1082,7 +1136,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
             return xmem_check_launch();
         }
         ConvArgs g = a;
-        g.in = V; g.w = d->w_winograd; g.out = Mt; g.res = nullptr; g.partial = nullptr;
+        g.in = V; g.w = pl.split ? reinterpret_cast<const float*>(d->w_winograd_split) : d->w_winograd;
+        g.a_presplit = 1; g.out = Mt; g.res = nullptr; g.partial = nullptr;
         g.B = 1; g.H = 1; g.W = (int)P; g.ldin = d->Cin; g.Ho = 1; g.Wo = (int)P; g.ldout = d->Cout; g.ldres = 0;
         g.KH = 1; g.KW = 1; g.stride = 1; g.pad = 0; g.K = d->Cin; g.M = (int)P; g.HoWo = (int)P;
         g.relu_in = 0; g.relu_out = 0; g.nk = pl.nk; g.splitk = 1; g.kt_per_split = pl.nk;

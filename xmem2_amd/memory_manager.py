@@ -79,12 +79,18 @@ class MemoryManager:
         obj_base = 0
         for gi in range(num_groups):
             # the stores that take part for this group, each contributing its LAST v_size(gi) elements
+            # (in long-term mode the list always has the three slots [long | temporary | permanent], the long one empty until
+            # the first consolidation / for groups it does not hold: the hint of the previous frame then keeps its layout when
+            # the long-term store comes into play - the frame after a consolidation is a hinted call like any other)
             stores = []
-            if lt is not None and gi < lt.num_groups:
-                stores.append(lt)
+            if self.enable_long_term:
+                stores.append(lt if (lt is not None and gi < lt.num_groups) else None)
             stores += [tmp, perm]
             segs, vsegs = [], None
             for st in stores:
+                if st is None:
+                    segs.append((None, None))
+                    continue
                 vs = st.get_v_size(gi)
                 start = st.size - vs
                 segs.append((st.key_rows(start), st.shrinkage_rows(start)))
@@ -105,7 +111,7 @@ class MemoryManager:
                     first = lt.size
                 tmp.update_usage_from(w, idx, first)            # usage[:, long : long + temp]; never permanent
             n_obj = stores[-1].value_rows(gi).shape[0]
-            vsegs = [[st.value_rows(gi)[o] for st in stores] for o in range(n_obj)]
+            vsegs = [[(st.value_rows(gi)[o] if st is not None else None) for st in stores] for o in range(n_obj)]
             ops.readout_sparse(vsegs, w, idx, self.CV, out, out_ld, obj_stride,
                                out_off=out_off + obj_base * obj_stride)
             obj_base += n_obj

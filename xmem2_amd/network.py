@@ -40,8 +40,8 @@ class XMem:
         # 'fp32' (default: the parity contract) | 'fp16' (opt-in: Winograd-domain operands in fp16, fp32 accumulation -
         # the counterpart of the reference's autocast loop; the permanent-memory preload stays fp32 as in run_on_video.py:66)
         self.precision = config.get('precision', os.environ.get('XMEM_PRECISION', 'fp32'))
-        if self.precision not in ('fp32', 'fp16'):
-            raise ValueError(f"config['precision'] must be 'fp32' or 'fp16', got {self.precision!r}")
+        if self.precision not in ops.PRECISIONS:
+            raise ValueError(f"config['precision'] must be one of {ops.PRECISIONS}, got {self.precision!r}")
         self._stages = collections.OrderedDict()     # captured stages, least recently replayed first
         self._zeros = {}
         self._owner_free, self._owner_next = [], 0   # owner tokens of the cores driving this network (see acquire_owner)
@@ -244,7 +244,10 @@ class XMem:
         input / output buffers and replay it.  Kernels are launched through ctypes on torch's current stream, which
         is the capturing stream inside torch.cuda.graph, so they are captured like any other launch."""
         prec = self._call_precision or self.precision
-        if not self.use_graphs or ops.eager_only():
+        only = os.environ.get('XMEM_PRECISION_ONLY')          # tools: restrict a non-default precision to one stage kind
+        if only and prec != 'fp32' and name != only:
+            prec = 'fp32'
+        if not self.use_graphs or ops.eager_only() or name in os.environ.get('XMEM_EAGER_STAGES', '').split(','):
             with ops.precision(prec):
                 return fn(*inputs)
         full_key = (name, key, prec) + tuple(tuple(t.shape) if t is not None else None for t in inputs)

@@ -4,9 +4,10 @@ Everything here takes / returns torch CUDA tensors in the kernels' native layout
 ``[B,H,W,C]``, row-major memory rows ``[N,C]``) and launches on torch's current HIP stream.
 torch is plumbing only: allocation, streams.  No torch compute op is used on the product path.
 """
+import contextlib
 import ctypes as C
 import json
-import contextlib
+import math
 import os
 import sys
 import threading
@@ -132,12 +133,16 @@ def _req(t, name):
 # precision - the Winograd-domain operands are rounded to fp16 and multiplied on the fp16 MFMA with fp32 accumulation (the
 # counterpart of the reference's autocast loop, inference/run_on_video.py:76).  Set per call tree by XMem (`precision`).
 _PRECISION = 'fp32'
+PRECISIONS = ('fp32', 'fp16', 'fp32x')
+# 'fp32x' (opt-in, separately reported): SPLIT-OPERAND arithmetic - every fp32 operand of every GEMM-shaped convolution is
+# carried as two halfs (x = hi + lo, <= 2^-21 relative) and the four partial products run on v_mfma_f32_32x32x16_f16 with fp32
+# accumulation (csrc/conv_mfma.hip, SPLIT kernels).  Same tensors, same bytes, fp32-class results; 1/4 of the fp32 MFMA cycles.
 
 
 class precision:
     def __init__(self, mode):
-        if mode not in ('fp32', 'fp16'):
-            raise ValueError(f'unknown precision {mode!r} (fp32 | fp16)')
+        if mode not in PRECISIONS:
+            raise ValueError(f'unknown precision {mode!r} ({" | ".join(PRECISIONS)})')
         self.mode = mode
 
     def __enter__(self):
@@ -151,7 +156,8 @@ class precision:
 
 class ConvWeights:
     """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
-    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu', 'wu_f16', 'wu4')
+    __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu', 'wu_f16', 'wu4',
+                 'sp_shift', 'scale_sp', 'w_sp', 'wu_sp', 'wu4_sp')
 
     def __init__(self, w, scale, shift, stride, pad, cin_true=None, winograd=True):
         self.w, self.scale, self.shift = w, scale, shift
@@ -161,11 +167,43 @@ class ConvWeights:
         self.wu = None
         self.wu_f16 = None
         self.wu4 = None                  # F(4x4,3x3) operand, built on first use (only the large layers take that path)
+        self.sp_shift = None             # 'fp32x' mode only: split operands (built on first use), see ensure_split
+        self.scale_sp = self.w_sp = self.wu_sp = self.wu4_sp = None
         if winograd and self.kh == 3 and self.kw == 3 and stride == 1 and pad == 1 and self.cin % 32 == 0 \
                 and self.cout % 4 == 0 and self.cout >= 32:
             self.wu = winograd_weights(w)
             if self.cin % 64 == 0:
                 self.wu_f16 = self.wu.to(torch.float16).contiguous()      # reduced-precision mode only
+
+
+    def ensure_split(self):
+        """Split-operand forms of the weights for the 'fp32x' mode: every array the kernels may contract (direct, F(2x2), F(4x4))
+        times ONE power of two 2^s per layer (so that the low halves stay in fp16's normal range), each group of four input
+        channels stored as [hi x 4 | lo x 4] halfs; `scale_sp` = scale * 2^-s undoes the factor exactly in the epilogue."""
+        if self.sp_shift is None:
+            forms = [t for t in (self.w, self.wu, self.wu4) if t is not None]
+            amax = max(float(t.abs().max()) for t in forms)
+            s = 0 if not (amax > 0 and math.isfinite(amax)) else max(-8, min(24, int(math.floor(math.log2(1024.0 / amax)))))
+            self.sp_shift = s
+            self.scale_sp = (self.scale * (2.0 ** -s)).contiguous()
+            self.w_sp = split_pack(self.w, s)
+            self.wu_sp = split_pack(self.wu, s) if self.wu is not None else None
+        if self.wu4 is not None and self.wu4_sp is None:
+            if float(self.wu4.abs().max()) * 2.0 ** self.sp_shift > 3.0e4:      # built after the shift was chosen and larger than planned
+                raise RuntimeError('split operand out of the fp16 range: build the F(4x4) operand before ensure_split()')
+            self.wu4_sp = split_pack(self.wu4, self.sp_shift)
+
+
+def split_pack(w, shift=0):
+    """float32 [..., C] (C % 4 == 0) -> float16 [..., 2C]: per four channels [hi0..hi3 | lo0..lo3] of w * 2^shift, hi = the
+    nearest half, lo = the nearest half of the remainder (|w 2^shift - hi - lo| <= 2^-22 |w 2^shift| or 3e-8 absolute)."""
+    ws = w.float() * (2.0 ** shift)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    c = w.shape[-1]
+    hi4 = hi.reshape(*w.shape[:-1], c // 4, 4)
+    lo4 = lo.reshape(*w.shape[:-1], c // 4, 4)
+    return torch.cat([hi4, lo4], -1).reshape(*w.shape[:-1], 2 * c).contiguous()
 
 
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
@@ -289,8 +327,15 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         raise RuntimeError(f'conv2d: weight expects Cin={cw.cin}, got {cin}')
     Ho = (H + 2 * cw.pad - cw.kh) // cw.stride + 1
     Wo = (W + 2 * cw.pad - cw.kw) // cw.stride + 1
+    guard = None
     if out is None:
-        out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float32, device=x.device)
+        if _GUARD and not torch.cuda.is_current_stream_capturing():      # tools: sentinel zones around the output (XMEM_GUARD=1)
+            n, G = B * Ho * Wo * cw.cout, 65536
+            flat = torch.full((n + 2 * G,), 12345.0, dtype=torch.float32, device=x.device)
+            out = flat[G:G + n].view(B, Ho, Wo, cw.cout)
+            guard = (flat, G, n)
+        else:
+            out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float32, device=x.device)
         out_ld = cw.cout
     elif out_ld is None:
         out_ld = out.shape[-1]
@@ -337,10 +382,47 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         if cw.wu4 is None and cw.wu is not None:
             cw.wu4 = winograd4_weights(cw.w)
         d.w_winograd4 = cw.wu4.data_ptr() if cw.wu4 is not None else None
+    d.arith = 0
+    d.w_split = d.w_winograd_split = d.w_winograd4_split = None
+    if _PRECISION == 'fp32x' and cw.cout > 1:
+        # split-operand arithmetic for every GEMM-shaped path (the Cout = 1 mask head is a GEMV on the fp32 VALU)
+        if cw.sp_shift is None or (cw.wu4 is not None and cw.wu4_sp is None):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('conv2d: split operands must be built before graph capture (run the stage eagerly once)')
+            if cw.sp_shift is None and cw.wu is not None and cw.wu4 is None and WINO4:
+                cw.wu4 = winograd4_weights(cw.w)          # so that ONE power of two covers every form of this layer
+            cw.ensure_split()
+        d.arith = 1
+        d.w_split = cw.w_sp.data_ptr()
+        d.w_winograd_split = cw.wu_sp.data_ptr() if cw.wu_sp is not None else None
+        d.w_winograd4_split = cw.wu4_sp.data_ptr() if (cw.wu4_sp is not None and d.w_winograd4) else None
+        d.scale = cw.scale_sp.data_ptr()
     d.plan_tile, d.plan_splitk = plan
+    if _SPLIT_CHECK and d.arith == 1 and not torch.cuda.is_current_stream_capturing():
+        # tools: the same call in fp32 first, then compare (XMEM_SPLIT_CHECK=1; synchronises)
+        d.arith, sc = 0, d.scale
+        d.scale = cw.scale.data_ptr()
+        need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
+        ws = workspace(need, x.device, 'conv') if need else None
+        check(lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()))
+        want = out.clone()
+        d.arith, d.scale = 1, sc
     need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
-    ws = workspace(need, x.device, 'conv') if need else None
+    ws = workspace(need + (1 << 20 if guard else 0), x.device, 'conv') if need else None
+    if guard and ws is not None:
+        ws[need:need + (1 << 20)].fill_(0x5a)
     check(lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()))
+    if guard:
+        flat, G, n = guard
+        bad_lo, bad_hi = int((flat[:G] != 12345.0).sum()), int((flat[G + n:] != 12345.0).sum())
+        bad_ws = int((ws[need:need + (1 << 20)] != 0x5a).sum()) if ws is not None else 0
+        if bad_lo or bad_hi or bad_ws:
+            print(f'[guard] {key} plan={tuple(plan)} arith={d.arith}: {bad_lo} floats written BEFORE the output, {bad_hi} AFTER it, '
+                  f'{bad_ws} bytes past the workspace', file=sys.stderr)
+    if _SPLIT_CHECK and d.arith == 1 and not torch.cuda.is_current_stream_capturing():
+        err = float((out - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+        print(f'[split check] {key} plan={tuple(plan)} in_ld={ldin} max |fp32x - fp32| / max|fp32| = {err:.2e}' +
+              ('   <-- MISMATCH' if not err < 1e-3 else ''), file=sys.stderr)
     if RECORD is not None:
         RECORD.append(('conv', key, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true,
                        lambda: lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()), (x, out, res, cw, ws)))
@@ -520,6 +602,8 @@ def nchw_to_nhwc(x):
 # ---------------------------------------------------------------------------------------------
 
 _AFF_STATS = bool(os.environ.get('XMEM_AFFINITY_STATS'))
+_SPLIT_CHECK = bool(os.environ.get('XMEM_SPLIT_CHECK'))
+_GUARD = bool(os.environ.get('XMEM_GUARD'))
 
 
 def affinity_topk(segments, qk, qe, top_k, want_sim=False, hint=None):
