@@ -184,7 +184,16 @@ typedef struct {
     const float* key;        /* [n][C_k] rows */
     const float* shrinkage;  /* [n] or NULL (treated as 1, memory_util.py:36-37) */
     int n;                   /* elements in this segment (may be 0) */
+    const void* rows16;      /* optional [n][XMEM_ROWS16_HALFS] IEEE halfs: the operand rows of the fp16 filter for these keys, kept
+                                by the caller across calls (xmem_affinity_rows16 makes them; they depend on key and shrinkage only).
+                                NULL: the call derives them into its workspace.  Never changes a result. */
 } xmem_key_segment;
+#define XMEM_ROWS16_HALFS 144
+
+/* Filter operand rows of `n` memory elements (csrc/affinity_common.hpp: [ms/8 x^2 | ms/8 x | 16 augmentation terms] in fp16,
+ * 288 bytes per element).  A store calls it once per appended / replaced block and hands the rows to xmem_affinity_topk_hinted
+ * through xmem_key_segment.rows16 - the per-call rows kernel and its N x 288 bytes of writes disappear from the frame loop. */
+int xmem_affinity_rows16(const float* key, const float* shrinkage, int n, void* rows16, void* stream);
 
 /* segments are searched as one virtual concatenation (long | temporary | permanent in the reference's
  * order, memory_manager.py:82-83); out indices are positions in that concatenation.
@@ -201,6 +210,12 @@ int xmem_affinity_topk(const xmem_key_segment* segs_host, int n_seg,
  * candidate counts [HW] int32, the per-128-query-tile flags of the two filter passes [2][ceil(HW/128)] int32 and the per-query
  * lower bounds [HW] float of the last xmem_affinity_topk_hinted call that took the fp16-filter path. */
 int xmem_affinity_debug_offsets(int n_total, int HW, size_t* count_off, size_t* flag_off, size_t* bound_off);
+
+/* Measurement aid: two HIP events (hipEvent_t, created with timing enabled) that the following xmem_affinity_topk_hinted calls
+ * record on their stream right before and right after the pass-1 launch of the fp16 filter kernel - the kernel bench.py's
+ * `roofline` object is about (the reference times the whole step with perf_counter, inference/run_on_video.py:106-113).
+ * NULL, NULL turns it off.  Process-wide, not thread-safe, no effect on results. */
+int xmem_affinity_profile_events(void* before_filter, void* after_filter);
 
 /* Same function with an optional HINT: `idx` are the out_idx [HW][top_k] of an earlier call on the same list of stores (the
  * previous frame of the video), `seg_n` the segment sizes of that call, `grid_w` the width of the stride-16 query grid (0: do not

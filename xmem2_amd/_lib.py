@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
 
 
 class KeySegment(C.Structure):
-    _fields_ = [('key', C.c_void_p), ('shrinkage', C.c_void_p), ('n', C.c_int)]
+    _fields_ = [('key', C.c_void_p), ('shrinkage', C.c_void_p), ('n', C.c_int), ('rows16', C.c_void_p)]
 
 
 class AffinityHint(C.Structure):
@@ -69,6 +69,8 @@ _SIGS = {
     'xmem_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'xmem_affinity_topk_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'xmem_affinity_debug_offsets': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    'xmem_affinity_profile_events': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'xmem_affinity_rows16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'xmem_affinity_topk': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'xmem_affinity_topk_hinted': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -1150,10 +1150,11 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         pos_map[i] = ns;
         a.seg[ns].key = segs[i].key; a.seg[ns].shr = segs[i].shrinkage; a.seg[ns].n = segs[i].n;
         a.seg[ns].base = base; a.seg[ns].tile0 = tiles; a.seg[ns].pad = 0;
+        a.seg[ns].rows16 = reinterpret_cast<const _Float16*>(segs[i].rows16);
         tiles += cdiv(segs[i].n, AFF_ROWS); base += segs[i].n; ++ns;
     }
     if (base < top_k) return XMEM_ERR_TOPK;
-    for (int i = ns; i < XMEM_MAX_SEGMENTS; ++i) { a.seg[i].key = nullptr; a.seg[i].shr = nullptr; a.seg[i].n = 0; a.seg[i].base = base; a.seg[i].tile0 = tiles; a.seg[i].pad = 0; }
+    for (int i = ns; i < XMEM_MAX_SEGMENTS; ++i) { a.seg[i].key = nullptr; a.seg[i].shr = nullptr; a.seg[i].n = 0; a.seg[i].base = base; a.seg[i].tile0 = tiles; a.seg[i].pad = 0; a.seg[i].rows16 = nullptr; }
     const WsLayout wl = ws_layout(HW, base);
     if (!workspace || workspace_bytes < wl.total) return XMEM_ERR_WORKSPACE;
     char* ws = reinterpret_cast<char*>(workspace);

@@ -9,7 +9,7 @@
 
 typedef unsigned long long u64;
 
-struct SegDev { const float* key; const float* shr; int n; int base; int tile0; int pad; };
+struct SegDev { const float* key; const float* shr; int n; int base; int tile0; int pad; const _Float16* rows16; };   // rows16: fp16 filter only
 
 // Segment lookup with a PER-LANE index: p.seg[i] for a constant i is a scalar kernel-argument load, p.seg[lane_value] would be a
 // vector memory load from the argument buffer (one more ~1 us dependent latency) - so select field by field instead.
@@ -76,7 +76,7 @@ struct Filter16Args {
     int splits, tiles_per_split;     // set by aff_filter16_launch
     const _Float16* qop16;           // [HW][F16_K] query operand rows          } written by the bound kernel
     const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), 0, 0, 0   }
-    _Float16* rows16;                // [N + 32][F16_K] memory operand rows, written by the rows kernel of the same launch
+    _Float16* rows16;                // workspace [N + 32][F16_K] for segments whose caller keeps no operand rows (seg[i].rows16 == 0 on entry)
     float* tau;                      // [HW] valid lower bound of the exact k-th similarity (-inf: none yet); raised by the tighten pass
     u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
     int* gcand32; int* gcnt; int lcap; // [HW][lcap] candidate indices (aff_filter16_list_cap), [HW] zeroed by the bound kernel

@@ -59,15 +59,14 @@ __device__ __forceinline__ float exact_sim(const float* __restrict__ row, const 
 
 // ============================================================ rows ======================================================
 // fp16 operand rows of the memory (layout: affinity_common.hpp), 16 lanes per row.  Depends on (key, shrinkage) only.
-__global__ __launch_bounds__(256) void affinity_rows16_kernel(Filter16Args p, int n_total) {
+__global__ __launch_bounds__(256) void affinity_rows16_kernel(const float* __restrict__ key, const float* __restrict__ shr, int n,
+                                                             _Float16* __restrict__ rows16) {
     constexpr int CK = 64;
     const int l = threadIdx.x & 15;
-    const int gi = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (gi >= n_total) return;
-    const SegDev sd = seg_of_row(p, gi);
-    const int o = gi - sd.base;
-    const f32x4 x = *reinterpret_cast<const f32x4*>(sd.key + (size_t)o * CK + 4 * l);
-    const float msr = (sd.shr ? sd.shr[o] : 1.f) * 0.125f;
+    const int o = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (o >= n) return;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(key + (size_t)o * CK + 4 * l);
+    const float msr = (shr ? shr[o] : 1.f) * 0.125f;
     float sA = 0.f, sB = 0.f, mx = fabsf(msr);
     typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
     h16x4 h2, h1;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void affinity_rows16_kernel(Filter16Args p, in
     for (int d = 8; d > 0; d >>= 1) {
         sA += __shfl_xor(sA, d, 16); sB += __shfl_xor(sB, d, 16); mx = fmaxf(mx, __shfl_xor(mx, d, 16));
     }
-    _Float16* orow = p.rows16 + (size_t)gi * F16_K;
+    _Float16* orow = rows16 + (size_t)o * F16_K;
     *reinterpret_cast<h16x4*>(orow + 4 * l) = h2;
     *reinterpret_cast<h16x4*>(orow + CK + 4 * l) = h1;
     const float An = sqrtf(sA) * 1.0001f, Bn = sqrtf(sB) * 1.0001f, am = fabsf(msr);
@@ -106,13 +105,16 @@ __global__ __launch_bounds__(256) void affinity_rows16_kernel(Filter16Args p, in
 // grid (query tiles of 128, splits of the memory), 4 waves; wave w of split s takes tiles t_begin + w, + 4, ...
 // Per 32-row tile and 32-query block: 9 x v_mfma_f32_32x32x16_f16 give the UPPER estimates directly (augmented operands),
 // then 16 compares against tau whose lane masks ARE the output words.
+// PASS2 = the second pass over the flagged query tiles (its own kernel name: a trace tells the working launch from the one that
+// normally returns at once)
+template <bool PASS2>
 __global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(Filter16Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char Bh[F16_BQ * F16_LDB];
     __shared__ float s_tau[F16_BQ];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    if (p.only && p.only[blockIdx.x] == 0) return;              // pass 2: flagged query tiles only
+    if (PASS2 && p.only[blockIdx.x] == 0) return;               // pass 2: flagged query tiles only
     const int q0 = blockIdx.x * F16_BQ;
     const int split = blockIdx.y;
 
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(F
 #pragma unroll
         for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
             if (i < p.n_seg && tile >= p.seg[i].tile0) sg = i;
-        const int r = p.seg[sg].base + min((tile - p.seg[sg].tile0) * AFF_ROWS + l31, p.seg[sg].n - 1);
-        const _Float16* src = p.rows16 + (size_t)r * F16_K + lh * 8;
+        const int r = min((tile - p.seg[sg].tile0) * AFF_ROWS + l31, p.seg[sg].n - 1);
+        const _Float16* src = p.seg[sg].rows16 + (size_t)r * F16_K + lh * 8;
 #pragma unroll
         for (int t = 0; t < 9; ++t) dst[t] = *reinterpret_cast<const h16x8*>(src + 16 * t);
     };
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(F
 // bit (word r, lane j) of tile t, query block b  <->  query 32 b + (j & 31), row 32 (t - tile0) + (r & 3) + 8 (r >> 2) + 4 (j >> 5)
 #define SCAN_TILES 128
 #define SCAN_CAP 192
+template <bool PASS2>
 __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     __shared__ int s_cnt[32], s_base[32];
     __shared__ int s_buf[32][SCAN_CAP];
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     __shared__ volatile int s_dead;                              // every list of this block is full: nothing more to collect
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    if (p.only && p.only[b >> 2] == 0) return;                   // pass 2: flagged query tiles only
+    if (PASS2 && p.only[b >> 2] == 0) return;                    // pass 2: flagged query tiles only
     const int t0 = blockIdx.y * SCAN_TILES;
     const int nt = min(SCAN_TILES, p.total_tiles - t0);
     if (tid == 0) { s_dead = 0; s_nfull = 0; }
@@ -482,6 +485,23 @@ size_t aff_filter16_mask_bytes(int n_total, int HW) {
     return (size_t)cdiv(HW, F16_BQ) * 4 * tiles * 16 * sizeof(u64);
 }
 
+// Measurement aid (bench.py): two HIP events the next hinted calls record right before / after their pass-1 filter launch, on the
+// launch stream.  NULL, NULL turns it off.  Process-wide and not thread-safe: a tool's hook, not part of the data path.
+static hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
+extern "C" int xmem_affinity_profile_events(void* before_filter, void* after_filter) {
+    g_prof_ev[0] = reinterpret_cast<hipEvent_t>(before_filter);
+    g_prof_ev[1] = reinterpret_cast<hipEvent_t>(after_filter);
+    return XMEM_OK;
+}
+
+extern "C" int xmem_affinity_rows16(const float* key, const float* shrinkage, int n, void* rows16, void* stream) {
+    if (n < 0 || (n > 0 && (!key || !rows16))) return XMEM_ERR_BAD_ARG;
+    if (n == 0) return XMEM_OK;
+    hipLaunchKernelGGL(affinity_rows16_kernel, dim3(cdiv(n, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), key, shrinkage, n,
+                       reinterpret_cast<_Float16*>(rows16));
+    return xmem_check_launch();
+}
+
 int aff_filter16_launch(Filter16Args a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int qt = cdiv(a.HW, F16_BQ);
@@ -494,22 +514,30 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     for (int i = 0; i < a.n_seg; ++i) n_total += a.seg[i].n;
     const dim3 fgrid(qt, a.splits), sgrid(qt * 4, cdiv(a.total_tiles, SCAN_TILES));
     int rc;
-    hipLaunchKernelGGL(affinity_rows16_kernel, dim3(cdiv(n_total, 16)), dim3(256), 0, s, a, n_total);
-    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+    // operand rows: kept by the caller (xmem_key_segment.rows16), else derived into the workspace for this call
+    for (int i = 0; i < a.n_seg; ++i) {
+        if (a.seg[i].rows16 || a.seg[i].n == 0) continue;
+        _Float16* dst = a.rows16 + (size_t)a.seg[i].base * F16_K;
+        hipLaunchKernelGGL(affinity_rows16_kernel, dim3(cdiv(a.seg[i].n, 16)), dim3(256), 0, s, a.seg[i].key, a.seg[i].shr, a.seg[i].n, dst);
+        if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
+        a.seg[i].rows16 = dst;
+    }
     // pass 1: every tile, the caller's bound
     a.only = nullptr; a.flag_out = a.flag1;
-    hipLaunchKernelGGL(affinity_filter16_kernel, fgrid, dim3(256), 0, s, a);
+    if (g_prof_ev[0]) (void)hipEventRecord(g_prof_ev[0], s);       // tools: bracket the pass-1 filter (xmem_affinity_profile_events)
+    hipLaunchKernelGGL(affinity_filter16_kernel<false>, fgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_scan_kernel, sgrid, dim3(256), 0, s, a);
+    if (g_prof_ev[1]) (void)hipEventRecord(g_prof_ev[1], s);
+    hipLaunchKernelGGL(affinity_scan_kernel<false>, sgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     // pass 2: tiles with an overflowed list, with the bound their partial lists give (these three launches return at once
     // when nothing is flagged - the normal frame)
     a.only = a.flag1; a.flag_out = a.flag2;
     hipLaunchKernelGGL(affinity_refine_kernel<true>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_filter16_kernel, fgrid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(affinity_filter16_kernel<true>, fgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_scan_kernel, sgrid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(affinity_scan_kernel<true>, sgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_refine_kernel<false>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
     return xmem_check_launch();

@@ -12,9 +12,13 @@ to the LAST ``get_v_size(g)`` keys of the store.
 Row-major views are exposed for the kernels (``key_rows`` ...); the reference-shaped properties
 (``key`` ``1 x C x N`` ...) are zero-copy transposed views for callers such as the GUI gauges.
 """
+import os
+
 import torch
 
 from . import ops
+
+KEEP_ROWS16 = os.environ.get('XMEM_KEEP_ROWS16', '1') != '0'     # 0: the readout derives its fp16 operand rows per call (A/B runs)
 
 
 class _Arena:
@@ -66,6 +70,13 @@ class _Arena:
             dst.copy_(rows)
         self.n = need
 
+    def reserve(self, count):
+        """Make room for `count` more rows and count them in; the caller writes them (no fill kernel)."""
+        need = self.n + count
+        if need > self.cap:
+            self._alloc(max(need, 2 * self.cap, 4096))
+        self.n = need
+
     def keep(self, ranges):
         """Keep only the given (a, b) row ranges, in order (compaction in place)."""
         pos = 0
@@ -99,6 +110,7 @@ class KeyValueMemoryStore:
         self.device = device
         self._k = self._s = self._e = None
         self._use = self._life = None
+        self._r16 = None             # fp16 filter operand rows of the keys (288 B per element, csrc/affinity_common.hpp), kept in step with _k / _s
         self._v = []                 # one _Arena [n_obj_in_group, cap, Cv] per object group
         self.obj_groups = []
         self.all_objects = []
@@ -114,6 +126,15 @@ class KeyValueMemoryStore:
 
     def selection_rows(self, start=0):
         return self._e.rows(start) if self._has_e else None
+
+    def rows16(self, start=0):
+        """Operand rows of the readout's fp16 filter for elements [start, size): derived from (key, shrinkage) when elements are
+        added / replaced, moved with them when the store is sieved - never per frame."""
+        return self._r16.rows(start) if self._r16 is not None else None
+
+    def _refresh_rows16(self, a, b):
+        if self._r16 is not None and b > a:
+            ops.affinity_rows16(self._k.rows(a, b), self._s.rows(a, b) if self._has_s else None, self._r16.rows(a, b))
 
     def value_rows(self, gi):
         """[n_obj_in_group, v_size, Cv]"""
@@ -164,6 +185,7 @@ class KeyValueMemoryStore:
         self._k = _Arena([], ck, device)
         self._s = _Arena([], 0, device)
         self._e = _Arena([], ck, device)
+        self._r16 = _Arena([], ops.ROWS16_FLOATS, device) if (ck == 64 and KEEP_ROWS16) else None
         self._has_s, self._has_e = has_s, has_e
         if self.count_usage:
             self._use = _Arena([], 0, device)
@@ -182,6 +204,9 @@ class KeyValueMemoryStore:
             self._s.append(shrinkage, n)
         if selection is not None:
             self._e.append(selection, n)
+        if self._r16 is not None and n:
+            self._r16.reserve(n)                       # then derive from the rows just stored
+            self._refresh_rows16(self._k.n - n, self._k.n)
         if self.count_usage:
             self._use.append(0.0, n)
             self._life.append(1e-7, n)        # kv_memory_store.py:37-38
@@ -239,6 +264,7 @@ class KeyValueMemoryStore:
             self._s.rows(a, b).copy_(shrinkage)
         if self._has_e and selection is not None:
             self._e.rows(a, b).copy_(selection)
+        self._refresh_rows16(a, b)
 
     def remove_at(self, start: int, elem_size: int):
         """kv_memory_store.py:120-123."""
@@ -259,6 +285,8 @@ class KeyValueMemoryStore:
             s, e = self._resolve(arena.n, start, end)
             arena.keep([(0, s), (e, arena.n)])
         sieve(self._k)
+        if self._r16 is not None:
+            sieve(self._r16)
         if self.count_usage:
             sieve(self._use); sieve(self._life)
         if self._has_s:
@@ -282,7 +310,7 @@ class KeyValueMemoryStore:
         m = int(count.item())
         index = index[:m]
         for arena in [self._k, self._use, self._life] + ([self._s] if self._has_s else []) + \
-                     ([self._e] if self._has_e else []) + list(self._v):
+                     ([self._e] if self._has_e else []) + ([self._r16] if self._r16 is not None else []) + list(self._v):
             arena.take(index)
 
     def get_usage_rows(self):

@@ -89,14 +89,14 @@ class MemoryManager:
             segs, vsegs = [], None
             for st in stores:
                 if st is None:
-                    segs.append((None, None))
+                    segs.append((None, None, None))
                     continue
                 vs = st.get_v_size(gi)
                 start = st.size - vs
-                segs.append((st.key_rows(start), st.shrinkage_rows(start)))
+                segs.append((st.key_rows(start), st.shrinkage_rows(start), st.rows16(start)))
             # the previous frame's top-k indices of this group bound the k-th similarity of this frame from below (a hint only:
             # the result does not depend on it, see xmem_affinity_topk_hinted)
-            sizes = [(k.shape[0] if k is not None else 0) for k, _ in segs]
+            sizes = [(sg[0].shape[0] if sg[0] is not None else 0) for sg in segs]
             hint = self._aff_hint.get(gi) if self.use_affinity_hint else None
             if hint is not None and (hint[0].shape[0] != qk.shape[0] or len(hint[1]) != len(sizes)):
                 hint = None

@@ -606,21 +606,39 @@ _SPLIT_CHECK = bool(os.environ.get('XMEM_SPLIT_CHECK'))
 _GUARD = bool(os.environ.get('XMEM_GUARD'))
 
 
+ROWS16_FLOATS = 72            # one fp16 filter operand row (144 halfs = 288 bytes) counted in floats
+
+
+def affinity_rows16(key, shrinkage, out):
+    """Filter operand rows of the memory elements `key` [n,Ck] / `shrinkage` [n] | None into out [n, 72] (float32-typed storage
+    of 144 halfs per row).  Stores call this when elements are added or replaced (kv_memory_store.py) and hand the rows to
+    affinity_topk, so the per-frame rows kernel and its N x 288 bytes of writes are gone."""
+    n = key.shape[0]
+    if n == 0:
+        return out
+    if out.shape[0] != n or out.shape[1] != ROWS16_FLOATS or not out.is_contiguous() or not key.is_contiguous():
+        raise RuntimeError('affinity_rows16: expected contiguous key [n, Ck] and out [n, 72]')
+    check(load().xmem_affinity_rows16(ptr(_req(key, 'key')), ptr(shrinkage), n, ptr(out), stream_ptr()))
+    return out
+
+
 def affinity_topk(segments, qk, qe, top_k, want_sim=False, hint=None):
-    """segments: list of (key [n,Ck], shrinkage [n] | None).  Returns w [HW,k], idx [HW,k] (int32), sim | None.
+    """segments: list of (key [n,Ck], shrinkage [n] | None[, rows16 [n,72] | None]).  Returns w [HW,k], idx [HW,k] (int32), sim | None.
     hint: None or (idx [HW,k'] int32 of an earlier call on the same list of stores, its segment sizes, grid width) - only
     tightens the internal lower bound of the k-th similarity (xmem_affinity_topk_hinted); results do not depend on it."""
     lib = load()
     HW, ck = qk.shape
-    segs = [(k, s) if (k is not None and k.shape[0] > 0) else (None, None) for (k, s) in segments]   # empty stores keep their slot
-    n_total = sum(k.shape[0] for k, _ in segs if k is not None)
+    segs = [(sg[0], sg[1], sg[2] if len(sg) > 2 else None) if (sg[0] is not None and sg[0].shape[0] > 0) else (None, None, None)
+            for sg in segments]                                            # empty stores keep their slot
+    n_total = sum(k.shape[0] for k, _, _ in segs if k is not None)
     if n_total < top_k:
         raise RuntimeError(f'selected index k out of range: top_k={top_k} > {n_total} memory elements')
     arr = (KeySegment * max(len(segs), 1))()
-    for i, (k, s) in enumerate(segs):
+    for i, (k, s, r16) in enumerate(segs):
         arr[i].key = k.data_ptr() if k is not None else None
         arr[i].shrinkage = s.data_ptr() if s is not None else None
         arr[i].n = k.shape[0] if k is not None else 0
+        arr[i].rows16 = r16.data_ptr() if (r16 is not None and k is not None and r16.shape[0] == k.shape[0]) else None
     w = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device)
     idx = torch.empty((HW, top_k), dtype=torch.int32, device=qk.device)
     sim = torch.empty((HW, top_k), dtype=torch.float32, device=qk.device) if want_sim else None
