@@ -61,6 +61,9 @@ WORKLOADS = {
     'b32dyn': dict(H=480, W=854, K=1, perm=22, mem_every=10, count_usage=True, n_query=32,
                    desc='B32-dyn: 480x854, 1 object, 22 permanent frames + mem_every=10 (T_max=10, T_min=5, long-term on): '
                         'encode_value + consolidation inside the timed loop'),
+    'b32motion': dict(H=480, W=854, K=1, perm=32, mem_every=10 ** 9, count_usage=False, n_query=32, motion=6, cut_every=16,
+                      desc='B32-motion: as B32, but the query frames move 6 px per frame and every 16th frame is a hard scene cut '
+                           '(mirrored, shifted scene): loose hint bounds, overflowing candidate lists, second filter pass'),
     'c3': dict(H=480, W=854, K=3, perm=1, mem_every=5, count_usage=True, n_query=32,
                desc='C3 stream: 480x854, 3 objects, 1 permanent frame, mem_every=5, long-term consolidation'),
     'c4': dict(H=720, W=1280, K=1, perm=256, mem_every=10, count_usage=True, n_query=16,
@@ -180,7 +183,22 @@ def run_gpu(args, device, rank, world):
 
     fetcher = AsyncMaskFetcher()                      # uint8 masks reach the host one frame behind the GPU (as run_on_video)
     KB = max(1, args.key_batch)
-    frame = lambda i: fr[base + (i % n_query)]
+    if wl.get('motion'):
+        # realistic motion for the readout's hint: frame i is the clip frame moved by `motion` px per frame (circular), and
+        # every `cut_every` frames the scene changes (mirrored + shifted) - the hint of the frame before a cut is useless
+        mv, ce = wl['motion'], wl['cut_every']
+        cache = {}
+
+        def frame(i):
+            j = i % (4 * n_query)
+            if j not in cache:
+                f = torch.roll(fr[base + (j % n_query)], shifts=mv * j, dims=2)
+                if (j // ce) % 2 == 1:
+                    f = torch.roll(torch.flip(f, dims=(1,)), shifts=137, dims=2)
+                cache[j] = f.contiguous()
+            return cache[j]
+    else:
+        frame = lambda i: fr[base + (i % n_query)]
 
     def hint(first):                                 # batched key encoder of frames [first, first+KB) on the side stream
         if not args.no_prefetch:
@@ -260,10 +278,74 @@ def run_gpu(args, device, rank, world):
         for kind, e0, e1, flop in events:
             d = taps.setdefault(kind, dict(ms=0.0, flop=0.0, calls=0))
             d['ms'] += e0.elapsed_time(e1); d['flop'] += flop; d['calls'] += 1
+            d.setdefault('each_ms', []).append(e0.elapsed_time(e1))
+    # ---- the dominant kernel itself (pass-1 fp16 filter) bracketed by HIP events inside the call, and the candidate statistics
+    # of the readout (list lengths, query tiles that needed the second pass): a few more frames of the same schedule, with a
+    # device sync per frame (not part of any reported rate)
+    filt, cand = None, None
+    if rank == 0 and not args.traced_child:
+        import ctypes as C
+        from xmem2_amd._lib import load
+        lib = load()
+        fe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 24))]
+        for a, b in fe:
+            a.record(); b.record()                                   # materialises the hipEvent_t handles
+        torch.cuda.synchronize(device)
+        ms, lens, flagged, tiles = [], [], 0, 0
+        start = args.warmup + args.steps + inst_frames
+        start = (start + KB - 1) // KB * KB
+        hint(start)
+        offs = [C.c_size_t(), C.c_size_t(), C.c_size_t()]
+        hw = (padded(wl['H']) // 16) * (padded(wl['W']) // 16)
+        for j, (a, b) in enumerate(fe):
+            lib.xmem_affinity_profile_events(C.c_void_p(a.cuda_event), C.c_void_p(b.cuda_event))
+            one_step(start + j)
+            lib.xmem_affinity_profile_events(None, None)
+            torch.cuda.synchronize(device)
+            try:
+                ms.append(a.elapsed_time(b))
+            except Exception:
+                pass
+            mm = core.memory
+            n_now = mm.temporary_work_mem.size + mm.permanent_work_mem.size + mm.long_mem.size
+            if lib.xmem_affinity_debug_offsets(n_now, hw, *[C.byref(x) for x in offs]) == 0:
+                ws = ops.workspace(0, device, 'affinity')
+                nt = (hw + 127) // 128
+                cnt = ws[offs[0].value:offs[0].value + 4 * hw].view(torch.int32).float()
+                fl = ws[offs[1].value:offs[1].value + 4 * nt].view(torch.int32)
+                lens.append((float(cnt.mean()), float(cnt.median()), float(cnt.max())))
+                flagged += int((fl != 0).sum()); tiles += nt
+        fetcher.drain()
+        if ms:
+            filt = dict(avg_ms=float(np.mean(ms)), median_ms=float(np.median(ms)), launches=len(ms))
+        if lens:
+            cand = dict(frames=len(lens), candidates_per_query_mean=float(np.mean([x[0] for x in lens])),
+                        candidates_per_query_median=float(np.median([x[1] for x in lens])),
+                        longest_list=float(max(x[2] for x in lens)),
+                        query_tiles_needing_second_pass=flagged / max(tiles, 1),
+                        note='final list length per query after the readout (after the second pass where it ran); '
+                             'fraction of 128-query tiles whose lists overflowed in pass 1')
     core.cancel_prefetch()
+    # ---- the reference surface's rate: step() on one frame at a time, no prefetch_keys (inference/run_on_video.py:98-113)
+    plain = None
+    if rank == 0 and not args.traced_child and not args.no_prefetch and args.plain_steps > 0:
+        saved, args.no_prefetch = args.no_prefetch, True
+        try:
+            n_plain = args.plain_steps
+            s0 = args.warmup + args.steps + inst_frames + 64
+            for i in range(2 * KB + (2 * me if me else 0)):          # captures the un-hinted graph variants
+                one_step(s0 + i)
+            fetcher.drain(); torch.cuda.synchronize(device)
+            t2 = time.perf_counter()
+            for i in range(n_plain):
+                one_step(s0 + 64 + i)
+            fetcher.drain(); torch.cuda.synchronize(device)
+            plain = dict(value=n_plain / (time.perf_counter() - t2), steps=n_plain)
+        finally:
+            args.no_prefetch = saved
     return dict(elapsed=elapsed, preload_s=preload_s, taps=taps, inst_frames=inst_frames, inst_elapsed=inst_elapsed,
                 masks=out_masks, core=core, frames=frames, masks_in=masks, sd=sd, n_query=n_query, base=base,
-                n_elems=n_elems, wl=wl, cfg=cfg)
+                n_elems=n_elems, wl=wl, cfg=cfg, filter_events=filt, candidates=cand, plain=plain, frame_fn=frame)
 
 
 # ---- rocprofv3 kernel trace of the timed region (child process) ------------------------------------------------
@@ -301,15 +383,18 @@ def parse_kernel_trace(path):
         raise RuntimeError('trace markers not found in the kernel trace')
     t0, t1 = marks[0][1], marks[-1][0]
     sel = [r for r in rows if t0 <= r[0] < t1 and not r[2].startswith('xmem_trace_marker_kernel')]
-    kern, fam = {}, {}
+    kern, fam, each = {}, {}, {}
     busy, last = 0, t0
     for s, e, name in sel:
         k = kern.setdefault(name, [0, 0]); k[0] += 1; k[1] += e - s
+        if family_of(name) == 'affinity':
+            each.setdefault(name, []).append(e - s)
         g = fam.setdefault(family_of(name), [0, 0]); g[0] += 1; g[1] += e - s
         a = max(s, last)
         if e > a:
             busy += e - a; last = e
-    return dict(window_ns=t1 - t0, busy_ns=busy, kernels=kern, families=fam, launches=len(sel))
+    return dict(window_ns=t1 - t0, busy_ns=busy, kernels=kern, families=fam, launches=len(sel),
+                median_ns={k: float(np.median(v)) for k, v in each.items()})
 
 
 def run_traced_child(args):
@@ -388,9 +473,10 @@ def run_cpu_baseline(res, args, device):
     plan = [(t, 1, 3) for t in sweep]
     n_total = sum(w + k for _, w, k in plan) + 3 + args.cpu_frames
     KB = max(1, args.key_batch)
-    idx_of = lambda i: base + (i % res['n_query'])
+    frame_fn = res['frame_fn']                                   # the workload's query frames (device tensors), as the timed region
+    cpu_frame = lambda i: frame_fn(i).cpu()
     # GPU stream first, driven exactly like the timed region (batched key-encoder hints when enabled)
-    dev = [torch.from_numpy(fr[idx_of(i)]).to(device) for i in range(n_total + 2 * KB)]
+    dev = [frame_fn(i).clone() for i in range(n_total + 2 * KB)]
     hint = (lambda a: gpu.prefetch_keys(dev[a:a + KB])) if not args.no_prefetch else (lambda a: None)
     hint(0)
     gpu_out = []
@@ -409,7 +495,7 @@ def run_cpu_baseline(res, args, device):
         for _ in range(n):
             i = pos[0]; pos[0] += 1
             t0 = time.perf_counter()
-            p = ref.step(torch.from_numpy(fr[idx_of(i)]), None, None)
+            p = ref.step(cpu_frame(i), None, None)
             m = R.post_process(p)
             ts.append(time.perf_counter() - t0)
             g, pg = gpu_out[i]
@@ -440,6 +526,38 @@ def run_cpu_baseline(res, args, device):
              frames_compared=len(ious), pixels_per_frame=wl['H'] * wl['W'], max_abs_prob_err_ds8=perr)
 
 
+def run_sampled_readout_check(res, device, n_pick=32):
+    """C4 / C5: the oracle cannot materialise N x HW (13 GB / 136 GB), so the readout the stream just used - hinted fp16 filter +
+    exact refine on the stream's own memory and hint - is checked on a random subset of the queries against the oracle's
+    get_similarity + top-k (model/memory_util.py:7-65) over ALL N memory elements."""
+    from oracle import cpu_ref as R
+    from xmem2_amd import ops
+    core, mm = res['core'], res['core'].memory
+    stores = [st for st in (mm.long_mem if mm.enable_long_term else None, mm.temporary_work_mem, mm.permanent_work_mem)]
+    segs = [((st.key_rows(), st.shrinkage_rows(), st.rows16()) if (st is not None and st.engaged() and st.size > 0) else (None, None, None))
+            for st in stores]
+    k, _, e = core.encode_frame_key(res['frame_fn'](5))
+    h, w = k.shape[-2:]
+    qk = k[0].permute(1, 2, 0).reshape(h * w, -1).contiguous()
+    qe = e[0].permute(1, 2, 0).reshape(h * w, -1).contiguous()
+    hint = mm._aff_hint.get(0)
+    if hint is not None and len(hint[1]) != len(segs):
+        hint = None
+    wgt, idx, sim = ops.affinity_topk(segs, qk, qe, TOPK, want_sim=True, hint=hint)
+    torch.cuda.synchronize(device)
+    pick = torch.randperm(h * w, generator=torch.Generator().manual_seed(11))[:n_pick]
+    mk = torch.cat([sg[0] for sg in segs if sg[0] is not None], 0).cpu()
+    ms = torch.cat([sg[1] for sg in segs if sg[0] is not None], 0).cpu()
+    ref = R.get_similarity(mk.t().unsqueeze(0), ms.view(1, 1, -1), qk.cpu()[pick].t().unsqueeze(0), qe.cpu()[pick].t().unsqueeze(0))
+    rv, ri = torch.topk(ref[0], TOPK, dim=0)
+    gv, gi = sim.cpu()[pick], idx.cpu().long()[pick]
+    same = (torch.sort(gi, 1)[0] == torch.sort(ri.t(), 1)[0]).all(1).float().mean()
+    return dict(kind='sampled readout check (the oracle cannot materialise N x HW at this size)', queries_sampled=int(n_pick),
+                memory_elements=int(mk.shape[0]), hinted=hint is not None,
+                topk_similarity_max_abs_err=float((gv - rv.t()).abs().max()),
+                identical_topk_index_sets=float(same), weights_sum_max_err=float((wgt.sum(1) - 1).abs().max()))
+
+
 # ---- entry -------------------------------------------------------------------------------------------------------
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -455,6 +573,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefetch', action='store_true', help='do not pipeline the coming frames\' key encoder')
     ap.add_argument('--key-batch', type=int, default=4, help='frames per batched key-encoder hint (prefetch_keys)')
+    ap.add_argument('--plain-steps', type=int, default=60, help='frames of the extra un-hinted pass that gives value_no_prefetch (0: skip)')
     ap.add_argument('--no-kernel-trace', action='store_true', help='skip the rocprofv3 child run (kernel tables of the timed region)')
     ap.add_argument('--trace-steps', type=int, default=60)
     ap.add_argument('--trace-timeout', type=int, default=420)
@@ -487,6 +606,9 @@ def main():
         raise SystemExit(f'rank {rank}: device {local} requested but only {torch.cuda.device_count()} visible')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
+    if world > 1:                                   # one process per GPU: cores next to the GPU, a bounded intra-op thread pool
+        from xmem2_amd.launch import pin_rank
+        pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), max_threads=8, device_index=local)
     backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -512,6 +634,7 @@ def main():
     elapsed = max_over_ranks(res['elapsed'], device)
     total_frames = sum_over_ranks(args.steps, device)
     per_rank = [args.steps / e for e in gather_over_ranks(res['elapsed'], device)]
+    preload_all = gather_over_ranks(res['preload_s'], device)
     fps = total_frames / elapsed
     if args.traced_child:
         print(json.dumps({'traced_child': True, 'fps_under_tracer': fps, 'steps': args.steps}), flush=True)
@@ -524,7 +647,13 @@ def main():
         ro = res['taps'].get('readout')
         aff_ms = aff['ms'] / nf if aff else None
         aff_gf = aff['flop'] / nf / 1e9 if aff else alg['similarity']
-        aff_tflops = (aff_gf / aff_ms) if aff_ms else None                     # GF / ms = TF/s
+        aff_tflops = (aff_gf / aff_ms) if aff_ms else None                     # GF / ms = TF/s (whole call, fp32-equivalent)
+        fe = res.get('filter_events')
+        calls_pf = (aff['calls'] / nf) if aff else 1.0
+        gf_per_call = aff_gf / max(calls_pf, 1e-9)
+        filt_tflops = (gf_per_call / fe['avg_ms']) if fe else None            # algorithmic F_sim of one call / the filter kernel's own time
+        q_pad = (alg['hw'] + 127) // 128 * 128
+        exec_gf = gf_per_call * (F16_K / 128.0) * (q_pad / alg['hw'])           # what the kernel really contracts: K = 144, queries padded to 128
         line = {
             'metric': (BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})') + PRECISION_LABEL[args.precision],
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -538,29 +667,47 @@ def main():
                        'control_plane': backend or 'none'},
             'per_rank_fps': per_rank,
             'roofline': {'bound': 'mfma',
-                         'kernel': 'xmem_affinity_topk_hinted: bound from the previous frame\'s matches -> fp16 filter on v_mfma_f32_32x32x16_f16 '
-                                   '(augmented operands: the contraction yields a rigorous UPPER estimate; one candidate bit per memory row x query) '
-                                   '-> scan -> exact fp32 refine of ~100 candidates per query.  Outputs bit-identical to the fp32 MFMA select, which '
-                                   'un-hinted calls and query tiles with overflowing candidate lists (scene cuts) still run',
-                         'note': 'achieved = SURVEY 8(d) algorithmic FLOPs of the reference\'s fp32 similarity (4*C_k*N*HW per call) / measured time of '
-                                 'the whole call; peak = dense fp32 MFMA, the pipe the contraction ran on until round 2.  The N x HW contraction now '
-                                 'runs on the fp16 matrix pipe (16x the rate) as a FILTER and only the surviving candidates are evaluated in fp32, '
-                                 'so frac is an fp32-equivalent rate and may exceed 1; per-kernel times and the filter\'s own executed-MFMA fraction '
-                                 'are under "kernels" (from the kernel trace)',
-                         'achieved': aff_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (aff_tflops / PEAK_FP32_MFMA_TFLOPS) if aff_tflops else None, 'traffic': None,
+                         'kernel': 'affinity_filter16_kernel<false> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
+                                   'of model/memory_util.py:7-39 on v_mfma_f32_32x32x16_f16 with augmented fp16 operands (the result is a rigorous '
+                                   'UPPER estimate; one candidate bit per memory row x query).  Around it in the same call: bound from the previous '
+                                   'frame\'s matches, scan of the bit matrix, [tighten + second filter / scan pass over query tiles whose lists '
+                                   'overflowed], exact fp32 refine of the listed candidates - outputs bit-identical to the fp32 MFMA select',
+                         'note': 'achieved = SURVEY 8(d) algorithmic FLOPs of the similarity (F_sim = 4*C_k*N*HW per call) / the average duration of '
+                                 'THIS kernel; peak = the dense fp16 MFMA peak, the pipe it runs on; frac = executed fraction of that pipe in algorithmic '
+                                 'FLOPs (executed_tflops counts the K = 144 operands and the queries padded to 128).  frac_fp32_equivalent is the round-2 '
+                                 'yardstick: F_sim / the time of the WHOLE call (all kernels) / the fp32 MFMA peak the contraction ran on before - it '
+                                 'exceeds 1 on large memories because the work is not done in fp32 any more',
+                         'achieved': filt_tflops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (filt_tflops / PEAK_F16_MFMA_TFLOPS) if filt_tflops else None, 'traffic': None,
+                         'kernel_avg_us': (1e3 * fe['avg_ms']) if fe else None, 'kernel_median_us': (1e3 * fe['median_ms']) if fe else None,
+                         'kernel_launches_timed': fe['launches'] if fe else None,
+                         'executed_tflops': (exec_gf / fe['avg_ms']) if fe else None,
+                         'algorithmic_gflop_per_call': gf_per_call,
+                         'frac_fp32_equivalent': (aff_tflops / PEAK_FP32_MFMA_TFLOPS) if aff_tflops else None,
+                         'call_tflops_fp32_equivalent': aff_tflops, 'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS,
                          'algorithmic_gflop_per_frame': aff_gf, 'ms_per_frame': aff_ms,
+                         'call_median_ms': float(np.median(aff['each_ms'])) if aff and aff.get('each_ms') else None,
                          'calls_per_frame': (aff['calls'] / nf) if aff else None,
-                         'measured': f'HIP events on the launch stream around every xmem_affinity_topk call (all of its kernels) inside an '
-                                     f'instrumented pass of the timed schedule ({res["inst_frames"]} frames; HIP graphs, two streams, '
-                                     f'batch-{args.key_batch} key hints): SURVEY 8(d) F_sim = 4*C_k*N*HW per call / that time'},
+                         'candidates': res.get('candidates'),
+                         'measured': f'kernel: HIP events recorded by the library on the launch stream right before / after the pass-1 filter launch '
+                                     f'(xmem_affinity_profile_events) over {fe["launches"] if fe else 0} frames of the timed schedule; whole call: HIP '
+                                     f'events around every xmem_affinity_topk_hinted call inside an instrumented pass ({res["inst_frames"]} frames; '
+                                     f'HIP graphs, two streams, batch-{args.key_batch} key hints)'},
             'readout': {'ms_per_frame': (ro['ms'] / nf) if ro else None,
                         'algorithmic_gflop_per_frame': (ro['flop'] / nf / 1e9) if ro else None,
                         'bound': 'hbm', 'algorithmic_bytes_per_frame': 4.0 * CV * wl['K'] * TOPK * alg['hw'] + 4.0 * CV * wl['K'] * alg['hw']},
             'frame_gflop': alg, 'whole_frame_tflops': alg['total'] / 1e3 * fps / world,
             'instrumented_pass_fps': (res['inst_frames'] / res['inst_elapsed']) if res['inst_elapsed'] else None,
-            'preload_s_per_rank': res['preload_s'],
+            'preload_s_per_rank': preload_all,
+            'slowest_rank_fps': min(per_rank), 'fastest_rank_fps': max(per_rank),
         }
+        if res.get('plain'):
+            # the reference's caller hands step() one frame at a time (inference/run_on_video.py:98-113): the same workload
+            # WITHOUT the prefetch_keys extra - the drop-in rate of the unchanged call sequence
+            line['value_no_prefetch'] = res['plain']['value']
+            line['value_no_prefetch_note'] = (f'frames/s of {res["plain"]["steps"]} frames through step() alone (no prefetch_keys hints: key encoder, '
+                                              'readout and decoder in one stream) after the timed region; `value` uses batched key hints, a streaming '
+                                              'extra the reference surface does not have')
         if world == 1 and not args.no_kernel_trace:
             tr, err = run_traced_child(args)
             if tr is None:
@@ -587,20 +734,20 @@ def main():
                                              'note': 'algorithmic = the DIRECT convolution\'s FLOPs (SURVEY 8d); Winograd F(2x2,3x3) layers execute 2.25x fewer MFMA FLOPs, so the executed-MFMA fraction is lower: see mfma_busy'}
                 if aff_us:
                     line['roofline']['timed_region_trace_us_per_frame'] = aff_us
-                    line['roofline']['frac_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
+                    line['roofline']['frac_fp32_equivalent_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
                     ks = {}
                     for k, v in tr['kernels'].items():
                         if family_of(k) == 'affinity' and v[0]:
-                            ks[k.split('(')[0]] = dict(launches_per_frame=v[0] / st, avg_us=v[1] / v[0] / 1e3, us_per_frame=v[1] / st / 1e3)
-                    fk = next((k for k in ks if 'filter16' in k), None)
-                    if fk:                                   # the filter's own matrix-pipe rate: executed fp16 FLOPs / its time
-                        calls = ks[fk]['launches_per_frame']
-                        n_mem = aff_gf * 1e9 / (4.0 * CK * alg['hw']) / max(aff['calls'] / nf, 1e-9) if aff else 0.0
-                        q_pad = (alg['hw'] + 127) // 128 * 128
-                        gf = 2.0 * n_mem * q_pad * F16_K / 1e9
-                        tf = gf / (ks[fk]['avg_us'] * 1e-3) if ks[fk]['avg_us'] else None
-                        ks[fk].update(executed_gflop_per_launch=gf, executed_tflops=tf, peak_tflops=PEAK_F16_MFMA_TFLOPS,
-                                      frac_of_f16_mfma_peak=(tf / PEAK_F16_MFMA_TFLOPS) if tf else None, calls_per_frame=calls)
+                            ks[k.split('(')[0]] = dict(launches_per_frame=v[0] / st, avg_us=v[1] / v[0] / 1e3, us_per_frame=v[1] / st / 1e3,
+                                                       median_us=tr['median_ns'].get(k, 0.0) / 1e3)
+                    # the pass-1 filter is its own instantiation (<false>): its executed fp16 FLOPs / its own time, from the trace
+                    fk = next((k for k in ks if 'filter16' in k and ('<false>' in k or 'ILb0' in k)), None)
+                    if fk and ks[fk]['avg_us']:
+                        tf = exec_gf / (ks[fk]['avg_us'] * 1e-3)
+                        ks[fk].update(executed_gflop_per_launch=exec_gf, executed_tflops=tf, peak_tflops=PEAK_F16_MFMA_TFLOPS,
+                                      frac_of_f16_mfma_peak=tf / PEAK_F16_MFMA_TFLOPS,
+                                      algorithmic_frac_of_f16_peak=(gf_per_call / (ks[fk]['avg_us'] * 1e-3)) / PEAK_F16_MFMA_TFLOPS)
+                        line['roofline']['kernel_avg_us_from_trace'] = ks[fk]['avg_us']
                     line['roofline']['kernels'] = ks
         pmc = committed_pmc(args.workload, args.precision)
         if pmc is not None:
@@ -616,6 +763,7 @@ def main():
             if args.workload in ('c4', 'c5'):
                 line['cpu_baseline'] = None
                 line['cpu_baseline_note'] = 'not run: the oracle materialises the N x HW affinity (13 GB / 136 GB per frame at this size)'
+                line['parity'] = run_sampled_readout_check(res, device)
             else:
                 cpu, parity = run_cpu_baseline(res, args, device)
                 line['cpu_baseline'] = cpu

@@ -44,7 +44,7 @@ def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref
     orig = ops.affinity_topk
 
     def spy(segs, qk, qe, top_k, want_sim=False, hint=None):
-        calls.append((sum(k.shape[0] for k, _ in segs if k is not None), hint is not None))
+        calls.append((sum(sg[0].shape[0] for sg in segs if sg[0] is not None), hint is not None))
         return orig(segs, qk, qe, top_k, want_sim=want_sim, hint=hint)
 
     ops.affinity_topk = spy

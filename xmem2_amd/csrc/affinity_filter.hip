@@ -23,6 +23,7 @@
 //          executes (bit-identical values), ranked, and soft-maxed as the merge kernel does: outputs bit-identical to the fp32
 //          path's.  Flagged tiles are computed by the fp32 select + merge of the same launch (affinity.hip), not here.
 #include "affinity_common.hpp"
+#include <stdlib.h>
 
 #define F16_BQ 128             // queries per filter workgroup (4 blocks of 32)
 #define F16_WAVES 4
@@ -473,7 +474,8 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
 
 // per-query candidate list length: ~N/64 (redundant memories keep thousands of near-ties for a few queries), 2048 .. 16384
 int aff_filter16_list_cap(int n_total) {
-    int c = 2048;
+    static const int cmin = getenv("XMEM_AFF_LCAP_MIN") ? atoi(getenv("XMEM_AFF_LCAP_MIN")) : 2048;     // tools: A/B of the floor
+    int c = cmin >= 256 && cmin <= 16384 ? cmin : 2048;
     while (c < n_total / 64 && c < 16384) c *= 2;
     return c;
 }
