@@ -96,6 +96,30 @@ size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d);
 int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Deterministic permanent-memory augmentations on the device: every augmented uint8 frame and float mask
+ * of one annotated frame in ONE launch.  Replaces the per-annotation loop of inference/run_on_video.py:231-242 over
+ * get_determenistic_augmentations(subset) (inference/frame_selection/frame_selection_utils.py:50-218): ColorJitter brightness
+ * (1.5 / 0.5), Grayscale(3), RandomPosterize(3), RandomAdjustSharpness(16), gaussian_blur(7) on the image with the mask kept;
+ * RandomAffine rotations / scalings / shears / translations on image (PIL: nearest, zero fill) AND mask (tensor branch:
+ * affine grid + grid_sample nearest).  img [H][W][3] uint8 (decoded frame at working size), mask [K][H][W] float or NULL,
+ * out_img [n_aug][H][W][3], out_mask [n_aug][K][H][W] or NULL.  The arithmetic of every step is restated in the precision
+ * the host libraries use (csrc/augment.hip); a load-time call (it synchronises the stream once), not for graph capture.
+ * ------------------------------------------------------------------------------------------ */
+enum { XMEM_AUG_BRIGHTNESS = 0, XMEM_AUG_POSTERIZE = 1, XMEM_AUG_GRAY = 2, XMEM_AUG_SHARPNESS = 3, XMEM_AUG_BLUR7 = 4, XMEM_AUG_AFFINE = 5 };
+#define XMEM_AUG_MAX 32
+typedef struct {
+    int type;                 /* XMEM_AUG_* */
+    float factor;             /* brightness / sharpness factor, posterize bits */
+    double image_matrix[6];   /* AFFINE, image side: PIL's inverse matrix (output pixel centre -> input coordinate),
+                                 torchvision _get_inverse_affine_matrix about the image centre */
+    float mask_grid[6];       /* AFFINE, mask side: (theta^T / [W/2, H/2]) as r00 r10 r20 r01 r11 r21 of the tensor branch's
+                                 _gen_affine_grid (matrix about the origin) */
+} xmem_aug_desc;
+size_t xmem_augment_workspace_bytes(int n_aug, int H, int W);
+int xmem_augment_frames(const uint8_t* img, const float* mask, int H, int W, int K, const xmem_aug_desc* descs, int n_aug,
+                        uint8_t* out_img, float* out_mask, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Pooling / resampling / gating kernels of the encoders and the decoder.
  * ------------------------------------------------------------------------------------------ */
 /* nn.MaxPool2d(3, stride 2, pad 1), model/resnet.py:123; in [B][H][W][C] -> out [B][Ho][Wo][C] */

@@ -121,3 +121,81 @@ def test_reduced_precision_mode_is_opt_in_and_close(synth_sd):
     iou = ((got == 1) & (ref_m == 1)).sum() / max(((got == 1) | (ref_m == 1)).sum(), 1)
     print(f'fp16 mode, 480p clip: IoU vs the reference masks {iou:.5f}, argmax mismatch {(got != ref_m).mean():.2e}, mean |dp| {perr:.2e}')
     assert iou >= 0.99 and perr < 5e-3
+
+
+def test_split_operand_mode_is_fp32_class(synth_sd):
+    """`precision='fp32x'` (opt-in, separately reported): every fp32 GEMM operand of the convolutions carried as two halfs
+    (x = hi + lo, <= 2^-21 relative), four partial products on v_mfma_f32_32x32x16_f16 with fp32 accumulation.  It must be as
+    accurate as the fp32 kernels - per layer against a float64 convolution (direct, pointwise with residual, stride 2, F(2x2),
+    F(4x4), channel-slice input) and end to end with the SAME gates as the fp32 path on the reference-recorded clips - and it
+    must really run the split kernels (bitwise different from fp32, yet within 2e-5 of it)."""
+    import ast
+    import numpy as np
+    import torch.nn.functional as F
+    from conftest import load_golden
+    from oracle import cpu_ref as R
+    from xmem2_amd import ops
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.network import XMem
+    from xmem2_amd.ops import ConvWeights
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    g = torch.Generator().manual_seed(11)
+    cases = [  # B, H, W, Cin, Cout, k, stride, plan, residual
+        (1, 60, 108, 256, 256, 3, 1, (19, 1), False), (1, 60, 108, 256, 256, 3, 1, (9, 1), True), (2, 31, 53, 64, 128, 3, 1, (3, 1), False),
+        (1, 60, 108, 256, 512, 1, 2, (3, 1), False), (4, 30, 54, 1024, 256, 1, 1, (6, 2), True), (1, 120, 216, 64, 256, 1, 1, (1, 1), True),
+        (1, 97, 131, 8, 64, 7, 2, (3, 1), False), (1, 30, 54, 260, 256, 1, 1, (3, 2), False)]
+    for (B, H, W, Cin, Cout, k, st, plan, with_res) in cases:
+        x = torch.randn(B, Cin, H, W, generator=g) * 1.5
+        w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+        sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+        Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+        res = torch.randn(B, Cout, Ho, Wo, generator=g) if with_res else None
+        ref = F.conv2d(x.double(), w.double(), None, st, k // 2) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+        if res is not None:
+            ref = (ref + res.double()).relu()
+        cw = ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), sc.cuda(), sh.cuda(), st, k // 2)
+        xin = x.permute(0, 2, 3, 1).contiguous().cuda()
+        rin = res.permute(0, 2, 3, 1).contiguous().cuda() if res is not None else None
+        outs = {}
+        for mode in ('fp32', 'fp32x'):
+            with ops.precision(mode):
+                outs[mode] = ops.conv2d(xin, cw, res=rin, relu_out=with_res, plan=plan).permute(0, 3, 1, 2).double().cpu()
+        scale = float(ref.abs().max())
+        e32, ex = float((outs['fp32'] - ref).abs().max()) / scale, float((outs['fp32x'] - ref).abs().max()) / scale
+        dx = float((outs['fp32x'] - outs['fp32']).abs().max()) / scale
+        print(f'{(B, H, W, Cin, Cout, k, st)} plan {plan}: err/scale fp32 {e32:.1e} fp32x {ex:.1e}; |fp32x - fp32| {dx:.1e}')
+        bound = 5e-5 if plan[0] >= 17 else 6e-6
+        assert ex < bound and ex < 3 * e32 + 1e-6, (e32, ex)
+        assert 0 < dx < 2e-5, 'the split kernels must have run (different bits) and stay fp32-close'
+    # saturation instead of inf / NaN for values beyond the fp16 range of the high half
+    big = torch.full((1, 8, 8, 64), 3.0e5).cuda()
+    cw1 = ConvWeights((torch.eye(64).view(64, 1, 1, 64) * 1.0).cuda(), torch.ones(64).cuda(), torch.zeros(64).cuda(), 1, 0)
+    with ops.precision('fp32x'):
+        y = ops.conv2d(big, cw1, plan=(3, 1))
+    assert bool(torch.isfinite(y).all()) and float(y.max()) <= 131072.0
+    # end to end: the fp32 path's own gates on the reference-recorded 480p clip and against the oracle on a dynamic clip
+    gold = load_golden('e2e_480p_1obj')
+    cfg = ast.literal_eval(str(gold['config']))
+    net = XMem(dict(cfg, precision='fp32x'), None).to('cuda').eval()
+    net.load_weights(synth_sd)
+    t = int(gold['shape'][0])
+    frames = torch.from_numpy(synthetic_frames(t, 480, 854)).cuda(); masks = torch.from_numpy(synthetic_masks(t, 1, 480, 854)).cuda()
+    core = InferenceCore(net, cfg)
+    core.set_all_labels([1])
+    core.put_to_permanent_memory(frames[0], masks[0])
+    out, probs = [], []
+    for ti in range(t):
+        if ti % 4 == 1:
+            core.prefetch_keys([frames[j] for j in range(ti, min(ti + 4, t))])        # the two-stream pipeline, as bench.py drives it
+        mk = masks[ti] if ti == 0 else None
+        p = core.step(frames[ti], mk, [1] if mk is not None else None, end=(ti == t - 1), do_not_add_mask_to_memory=(mk is not None))
+        out.append(ops.argmax_u8(p).cpu().numpy()); probs.append(p[:, 4::8, 4::8].cpu().numpy())
+    got, ref_m, probs = np.stack(out), gold['argmax'], np.stack(probs)
+    ious = [R.compute_array_iou(got[i], ref_m[i]) for i in range(t)]
+    mism = float((got != ref_m).mean())
+    d = np.abs(probs - gold['prob_ds8'])
+    srt = np.sort(gold['prob_ds8'], axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-2
+    print(f'fp32x, 480p clip vs the reference-recorded masks: min IoU {min(ious):.5f}, mismatch {mism:.2e}, mean |dp| {d.mean():.2e}')
+    assert min(ious) >= 0.999 and mism < 1e-4 and d.mean() < 5e-4
+    assert np.array_equal(probs.argmax(1)[clear], gold['prob_ds8'].argmax(1)[clear])

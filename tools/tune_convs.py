@@ -8,8 +8,14 @@ from xmem2_amd import ops, XMem, InferenceCore
 from xmem2_amd.synth import synthetic_state_dict, synthetic_frames, synthetic_masks
 import bench
 
-ops._plans = {} if os.environ.get('XMEM_RETUNE_ALL') else ops._load_plans()   # default: keep shipped plans, add new shapes
-net = XMem(dict(bench.b32_config()), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
+PREC = os.environ.get('XMEM_PRECISION', 'fp32')               # fp32x: measure the split-operand kernels -> conv_plans_fp32x.json
+if PREC == 'fp32x':
+    ops._load_plans(True)
+    if os.environ.get('XMEM_RETUNE_ALL'):
+        ops._plans_x = {}
+else:
+    ops._plans = {} if os.environ.get('XMEM_RETUNE_ALL') else ops._load_plans()   # default: keep shipped plans, add new shapes
+net = XMem(dict(bench.b32_config(), precision=PREC), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
 net.use_graphs = False
 for (H, W, K) in [(480, 854, 1), (480, 854, 2), (480, 854, 3), (720, 1280, 1), (240, 427, 1), (240, 427, 2), (1080, 1920, 1)]:
     cfg = bench.b32_config(); cfg['mem_every'] = 2
@@ -21,10 +27,11 @@ for (H, W, K) in [(480, 854, 1), (480, 854, 2), (480, 854, 3), (720, 1280, 1), (
     if K == 1:                                   # batched key-encoder hints (prefetch_keys): batch shapes incl. skip convs
         for B in (2, 4, 8):
             img = torch.zeros(B, (H + 15) // 16 * 16, (W + 15) // 16 * 16, 4, device='cuda')
-            net._encode_key_eager(img, True, True, False, True)
+            with ops.precision(PREC):
+                net._encode_key_eager(img, True, True, False, True)
     torch.cuda.synchronize()
-    print(H, W, K, 'plans so far', len(ops._tuned_now))
-n = ops.dump_tuned_plans(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/conv_plans.json')
+    print(H, W, K, 'plans so far', len(ops._tuned_now_x if PREC == 'fp32x' else ops._tuned_now))
+n = ops.dump_tuned_plans(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/conv_plans.json', split=(PREC == 'fp32x'))
 print('dumped', n)
-for k, v in sorted(ops._tuned_now.items()):
+for k, v in sorted((ops._tuned_now_x if PREC == 'fp32x' else ops._tuned_now).items()):
     print(k, v)

@@ -27,6 +27,10 @@ class ConvDesc(C.Structure):
                 ('arith', C.c_int), ('w_split', C.c_void_p), ('w_winograd_split', C.c_void_p), ('w_winograd4_split', C.c_void_p)]
 
 
+class AugDesc(C.Structure):
+    _fields_ = [('type', C.c_int), ('factor', C.c_float), ('image_matrix', C.c_double * 6), ('mask_grid', C.c_float * 6)]
+
+
 class KeySegment(C.Structure):
     _fields_ = [('key', C.c_void_p), ('shrinkage', C.c_void_p), ('n', C.c_int), ('rows16', C.c_void_p)]
 
@@ -69,6 +73,9 @@ _SIGS = {
     'xmem_nchw_to_nhwc': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'xmem_affinity_topk_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'xmem_affinity_debug_offsets': (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    'xmem_augment_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'xmem_augment_frames': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(AugDesc), C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     'xmem_affinity_profile_events': (C.c_int, [C.c_void_p, C.c_void_p]),
     'xmem_affinity_rows16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'xmem_affinity_topk': (C.c_int, [C.POINTER(KeySegment), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

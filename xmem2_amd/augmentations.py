@@ -105,6 +105,78 @@ class _Both(_Named):
         return affine_tensor(x, **self._kw) if torch.is_tensor(x) else affine_pil(x, **self._kw)
 
 
+def augmentation_specs(img_size=None, subset: str = None):
+    """The reference's fixed list (frame_selection_utils.py:49-218) as data: [(name, kind, params)], kind in {'brightness', 'gray',
+    'posterize', 'sharpness', 'blur', 'affine'}.  Both the host builders below and the device path (`augment_on_device`) read it."""
+    assert subset in {'best_3', 'best_3_with_symmetrical', 'best_all', 'original_only', 'all'}
+    translate_distance = (img_size[-1] // 5) if img_size is not None else 200
+    S = {
+        'bright': ('brightness', dict(factor=1.5)), 'dark': ('brightness', dict(factor=0.5)), 'gray': ('gray', {}),
+        'reduce_bits': ('posterize', dict(bits=3)), 'sharp': ('sharpness', dict(factor=16.0)), 'blur': ('blur', dict(kernel_size=7)),
+        'rotate_right': ('affine', dict(angle=30.0)), 'rotate_left': ('affine', dict(angle=-30.0)),
+        'translate_right': ('affine', dict(translate=(translate_distance, 0))),
+        'zoom_out': ('affine', dict(scale=0.5)), 'zoom_in': ('affine', dict(scale=1.5)),
+        'shear_right': ('affine', dict(shear=20)), 'shear_left': ('affine', dict(shear=-20)),
+    }
+    order = {
+        'best_3': ['blur', 'zoom_in', 'shear_right'],
+        'best_3_with_symmetrical': ['blur', 'zoom_in', 'shear_right', 'shear_left'],
+        'best_all': ['bright', 'dark', 'reduce_bits', 'sharp', 'blur', 'rotate_right', 'rotate_left', 'zoom_out', 'zoom_in',
+                     'shear_right', 'shear_left'],
+        'original_only': None,
+        'all': ['bright', 'dark', 'gray', 'reduce_bits', 'sharp', 'blur', 'rotate_right', 'rotate_left', 'translate_right', 'zoom_out',
+                'zoom_in', 'shear_right', 'shear_left'],
+    }[subset]
+    return None if order is None else [(n,) + S[n] for n in order]
+
+
+def augment_on_device(rgb_u8, mask, subset='best_all'):
+    """All augmented frames and masks of one annotated frame in ONE kernel launch (csrc/augment.hip).
+
+    rgb_u8: the decoded frame at working size, uint8 [H, W, 3] on the device; mask: float [K, H, W] on the device (or None).
+    Returns (frames uint8 [n, H, W, 3], masks: list of n tensors [K, H, W] - views of one buffer, the input mask itself for the
+    colour augmentations) in the reference's list order, or None for subset 'original_only'."""
+    import ctypes as C
+    from . import ops
+    from ._lib import AugDesc, check, load, ptr, stream_ptr
+    if not rgb_u8.is_cuda or rgb_u8.dtype != torch.uint8 or rgb_u8.dim() != 3 or rgb_u8.shape[2] != 3:
+        raise RuntimeError('augment_on_device: expected a device uint8 frame [H, W, 3]')
+    H, W = int(rgb_u8.shape[0]), int(rgb_u8.shape[1])
+    specs = augmentation_specs((3, H, W), subset)
+    if specs is None:
+        return None
+    n = len(specs)
+    descs = (AugDesc * n)()
+    TYPES = dict(brightness=0, posterize=1, gray=2, sharpness=3, blur=4, affine=5)
+    geometric = []
+    for i, (name, kind, kw) in enumerate(specs):
+        descs[i].type = TYPES[kind]
+        descs[i].factor = float(kw.get('factor', kw.get('bits', 0.0)))
+        geometric.append(kind == 'affine')
+        if kind == 'affine':
+            a = dict(angle=0.0, translate=(0, 0), scale=1.0, shear=0.0); a.update(kw)
+            tr = [float(t) for t in a['translate']]
+            m_img = _inverse_affine_matrix([W * 0.5, H * 0.5], a['angle'], tr, a['scale'], _shear2(a['shear']))
+            m_msk = _inverse_affine_matrix([0.0, 0.0], a['angle'], tr, a['scale'], _shear2(a['shear']))
+            theta = torch.tensor(m_msk, dtype=torch.float32).reshape(2, 3)
+            resc = theta.t() / torch.tensor([0.5 * W, 0.5 * H], dtype=torch.float32)          # [3, 2] as affine_tensor computes it
+            for j in range(6):
+                descs[i].image_matrix[j] = m_img[j]
+            for j, v in enumerate([resc[0, 0], resc[1, 0], resc[2, 0], resc[0, 1], resc[1, 1], resc[2, 1]]):
+                descs[i].mask_grid[j] = float(v)
+    img = rgb_u8.contiguous()
+    out_img = torch.empty((n, H, W, 3), dtype=torch.uint8, device=img.device)
+    K = 0 if mask is None else int(mask.shape[0])
+    msk = mask.to(dtype=torch.float32).contiguous() if mask is not None else None
+    out_mask = torch.empty((n, K, H, W), dtype=torch.float32, device=img.device) if msk is not None else None
+    lib = load()
+    need = lib.xmem_augment_workspace_bytes(n, H, W)
+    ws = ops.workspace(need, img.device, 'augment')
+    check(lib.xmem_augment_frames(ptr(img), ptr(msk), H, W, K, descs, n, ptr(out_img), ptr(out_mask), ptr(ws), need, stream_ptr()))
+    masks = [(out_mask[i] if geometric[i] else msk) for i in range(n)] if msk is not None else [None] * n
+    return out_img, masks
+
+
 def get_determenistic_augmentations(img_size=None, mask=None, subset: str = None):
     """frame_selection_utils.py:49-218, same name (sic), arguments and list order; returns [(img_aug, mask_aug), ...]."""
     assert subset in {'best_3', 'best_3_with_symmetrical', 'best_all', 'original_only', 'all'}

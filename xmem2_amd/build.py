@@ -9,11 +9,11 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'affinity_filter.hip', 'consolidate.hip', 'selector.hip']
+SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'affinity_filter.hip', 'consolidate.hip', 'selector.hip', 'augment.hip']
 HEADERS = ['common.hpp', 'affinity_common.hpp']
 LIB = os.path.join(CSRC, 'libxmem_hip.so')
 ARCH = 'gfx950'
-EXTRA_FLAGS = {}          # per-source compiler flags
+EXTRA_FLAGS = {'augment.hip': ['-ffp-contract=off']}      # per-source flags: the augmentation kernel rounds where the host libraries round
 # NO PACKED-FP32 VALU INSTRUCTIONS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel of this library.  Measured on MI355X
 # (round 3, tools/probes/victim_decoder_probe.py, hog_probe.py): an elementwise kernel built with them returned wrong values
 # in ~1e-4 of its elements (one 32-bit half of a packed result) WHILE a kernel issuing v_mfma_f32_32x32x16_f16 ran on another

@@ -309,6 +309,45 @@ class InferenceCore:
             mem.add_memory(key, shrinkage, value, self.all_labels, selection=sel, permanent=True, ti=ti, hw_shape=(h, w))
         return is_update
 
+    @_on_network_device
+    def put_many_to_permanent_memory(self, images, masks):
+        """Several annotated (or augmented) frames into the permanent memory through ONE batched key-encoder pass and ONE batched
+        value-encoder pass - the preload of inference/run_on_video.py:59-66 + :231-242 (12 frames per annotation with the
+        'best_all' augmentations) without 12 sequential passes.  Same result as `put_to_permanent_memory(image, mask)` frame by
+        frame in list order (to the round-off of batched convolution plans); always full fp32; frames of one shape, uint8
+        H x W x 3 or float 3 x H x W, masks K x H x W.  Not part of the reference surface."""
+        images, masks = list(images), list(masks)
+        if not images or len(images) != len(masks):
+            raise ValueError('put_many_to_permanent_memory: one mask per image')
+        if any(tuple(im.shape) != tuple(images[0].shape) for im in images) or any(tuple(m.shape) != tuple(masks[0].shape) for m in masks):
+            raise ValueError('put_many_to_permanent_memory: all frames (and all masks) must have one shape')
+        self._drop_prefetch()
+        net, mem = self.network, self.memory
+        dev = net.device
+        images = [im.to(dev) for im in images]
+        B = len(images)
+        u8 = images[0].dtype == torch.uint8
+        H0, W0 = (images[0].shape[0], images[0].shape[1]) if u8 else images[0].shape[-2:]
+        lw, uw, lh, uh = pad_amounts(H0, W0, 16)
+        image4 = torch.empty((B, H0 + lh + uh, W0 + lw + uw, 4), dtype=torch.float32, device=dev)
+        for i, im in enumerate(images):
+            _, hw, hw_p = self._pack(im, out=image4[i:i + 1])
+        net._need_weights()
+        with ops.precision('fp32'):
+            key, shrinkage, selection, f16, _, _ = net._encode_key_eager(image4, True, True)
+        h, w = f16.shape[1], f16.shape[2]
+        n = h * w
+        probs = [ops.aggregate_masks(self._pad_mask(m.to(dev), hw, hw_p))[1:] for m in masks]
+        value = net.encode_value_frames_nhwc(image4, f16, probs)
+        K = probs[0].shape[0]
+        for b in range(B):
+            mem.create_hidden_state(len(self.all_labels), hw_shape=(h, w), device=dev)
+            v = value[b * K:(b + 1) * K].reshape(K, n, value.shape[3])
+            sel = selection[b * n:(b + 1) * n] if self.enable_long_term else None
+            mem.add_memory(key[b * n:(b + 1) * n], shrinkage[b * n:(b + 1) * n], v, self.all_labels, selection=sel, permanent=True,
+                           ti=None, hw_shape=(h, w))
+        return B
+
     def remove_from_permanent_memory(self, frame_idx):
         self.memory.remove_from_permanent_memory(frame_idx)
 

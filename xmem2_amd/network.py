@@ -462,6 +462,31 @@ class XMem:
             hidden = ops.gru_gate(values, hidden)
         return value, hidden
 
+    def encode_value_frames_nhwc(self, image4, f16, masks):
+        """Value encoder over SEVERAL frames at once (the batched permanent-memory preload: an annotated frame and its
+        augmentations, inference/run_on_video.py:59-66,231-242): image4 [B,Hp,Wp,4], f16 [B,h,w,1024], masks = list of B tensors
+        [K,Hp,Wp] -> value [B*K,h,w,Cv] (frame-major).  No deep update (put_to_permanent_memory never makes one), eager,
+        in the network's full-precision arithmetic."""
+        self._need_weights()
+        W = self._w
+        B = image4.shape[0]
+        K = masks[0].shape[0]
+        with ops.precision('fp32'):
+            x = torch.empty((B * K,) + tuple(image4.shape[1:3]) + (8,), dtype=torch.float32, device=image4.device)
+            for b in range(B):
+                x[b * K:(b + 1) * K].copy_(ops.pack_value_input(image4[b:b + 1], masks[b]))
+            g = ops.conv2d(x, W['value_encoder.conv1'], relu_out=True)
+            g = ops.maxpool3x3s2(g)
+            g = self._stage(g, 'value_encoder.layer1', 2, self._basic)
+            g = self._stage(g, 'value_encoder.layer2', 2, self._basic)
+            g = self._stage(g, 'value_encoder.layer3', 2, self._basic)
+            _, h, w, cg = g.shape
+            cat = torch.empty((B * K, h, w, f16.shape[3] + cg), dtype=torch.float32, device=g.device)
+            for b in range(B):                        # each frame's own f16 in front of its objects' features
+                ops.copy_channels(f16[b:b + 1], cat[b * K:(b + 1) * K], 0)
+            ops.copy_channels(g, cat, f16.shape[3])
+            return self._fusion(cat, 'value_encoder.fuser', x=None)
+
     def new_decoder_input(self, K, h, w, device, slot=0, owner=0, h_out=None, has_skips=None):
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
         Once the matching decoder stage is captured this is its static input buffer (no copy before the replay)."""

@@ -240,24 +240,52 @@ def winograd_weights(w):
 # XMEM_CONV_AUTOTUNE=1 opts in to timing the candidates at first use (tools/tune_convs.py does, to refresh conv_plans.json).
 AUTOTUNE = os.environ.get('XMEM_CONV_AUTOTUNE', '0') == '1'
 _PLAN_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_plans.json')
+_PLAN_FILE_X = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_plans_fp32x.json')   # measured with the split kernels
 _plans = None
+_plans_x = None
 _tuned_now = {}
+_tuned_now_x = {}
 
 
-def _load_plans():
-    global _plans
+def _read_plan_file(path):
+    if os.path.exists(path):
+        try:
+            return {k: tuple(v) for k, v in json.load(open(path)).items()}
+        except Exception:
+            pass
+    return {}
+
+
+def _load_plans(split=False):
+    """Plan table of the fp32 kernels, or (split=True) of the split-operand kernels: the GEMMs are ~4x cheaper there, so other
+    tiles win; shapes the fp32x table does not list fall back to the fp32 entry."""
+    global _plans, _plans_x
     if _plans is None:
-        _plans = {}
-        if os.path.exists(_PLAN_FILE):
-            try:
-                _plans = {k: tuple(v) for k, v in json.load(open(_PLAN_FILE)).items()}
-            except Exception:
-                _plans = {}
-    return _plans
+        _plans = _read_plan_file(_PLAN_FILE)
+    if not split:
+        return _plans
+    if _plans_x is None:
+        _plans_x = _read_plan_file(_PLAN_FILE_X)
+    return _plans_x
 
 
-def dump_tuned_plans(path):
+def _lookup_plan(key, split):
+    if split:
+        p = _load_plans(True).get(key) or _tuned_now_x.get(key)
+        if p is not None or AUTOTUNE:                 # the tuner measures the split kernels instead of inheriting the fp32 entry
+            return p
+        return _load_plans().get(key) or _tuned_now.get(key)
+    return _load_plans().get(key) or _tuned_now.get(key)
+
+
+def dump_tuned_plans(path, split=False):
     """Write every plan known to this process (shipped + tuned now) - used to refresh conv_plans.json."""
+    if _PRECISION == 'fp32x' or split:
+        allp = dict(_load_plans(True))
+        allp.update(_tuned_now_x)
+        with open(path, 'w') as f:
+            json.dump({k: list(v) for k, v in sorted(allp.items())}, f, indent=0)
+        return len(allp)
     allp = dict(_load_plans())
     allp.update(_tuned_now)
     if WINO4 and (os.environ.get('XMEM_RETUNE_ALL') or '__tuned_with_f4__' in allp):
@@ -282,6 +310,9 @@ def _tune_conv(lib, d, x_device, cw=None):
             if cw.wu4 is None:
                 cw.wu4 = winograd4_weights(cw.w)
             d.w_winograd4 = cw.wu4.data_ptr()
+            if d.arith == 1:
+                cw.ensure_split()
+                d.w_winograd4_split = cw.wu4_sp.data_ptr()
             cands += [(t + 16, cfg) for t, cfg in tiles.items()]
     for tile, (bm, bn, bk) in cands:
         if bn == 128 and d.Cout <= 64 and tile != 15:
@@ -355,8 +386,24 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         d.w_winograd_f16 = cw.wu_f16.data_ptr()
         plan = (16, 1)                       # the library falls back to the fp32 Winograd tile if its own conditions fail
     key = f'{B}x{H}x{W}x{cin}/{ldin}->{cw.cout}/{out_ld} k{cw.kh}s{cw.stride}p{cw.pad} r{int(res is not None)}{int(relu_in)}{int(relu_out)}'
+    d.arith = 0
+    d.w_split = d.w_winograd_split = d.w_winograd4_split = None
+    split = _PRECISION == 'fp32x' and cw.cout > 1
+    if split:
+        # split-operand arithmetic for every GEMM-shaped path (the Cout = 1 mask head is a GEMV on the fp32 VALU)
+        if cw.sp_shift is None or (cw.wu4 is not None and cw.wu4_sp is None):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('conv2d: split operands must be built before graph capture (run the stage eagerly once)')
+            if cw.sp_shift is None and cw.wu is not None and cw.wu4 is None and WINO4:
+                cw.wu4 = winograd4_weights(cw.w)          # so that ONE power of two covers every form of this layer
+            cw.ensure_split()
+        d.arith = 1
+        d.w_split = cw.w_sp.data_ptr()
+        d.w_winograd_split = cw.wu_sp.data_ptr() if cw.wu_sp is not None else None
+        d.w_winograd4_split = cw.wu4_sp.data_ptr() if cw.wu4_sp is not None else None    # taken only by an F(4x4) plan
+        d.scale = cw.scale_sp.data_ptr()
     if plan is None:
-        plan = _load_plans().get(key) or _tuned_now.get(key)
+        plan = _lookup_plan(key, split)
     if plan is None:
         plan = (0, 0)
         if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
@@ -366,7 +413,7 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             # Winograd with the 64x64 GEMM tile - F(4x4) from 1/8 resolution of 480p up, F(2x2) below - instead of the direct
             # form (deterministic: same shape -> same plan on every machine)
             plan = (19, 1) if (WINO4 and Ho * Wo >= WINO4_MIN_PIXELS) else (9, 1)
-        _tuned_now[key] = plan
+        (_tuned_now_x if split else _tuned_now)[key] = plan
     d.w_winograd4 = None
     if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32' \
             and '__tuned_with_f4__' not in _load_plans():      # a table tuned against F(4x4) already says which layers take it
@@ -382,21 +429,11 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         if cw.wu4 is None and cw.wu is not None:
             cw.wu4 = winograd4_weights(cw.w)
         d.w_winograd4 = cw.wu4.data_ptr() if cw.wu4 is not None else None
-    d.arith = 0
-    d.w_split = d.w_winograd_split = d.w_winograd4_split = None
-    if _PRECISION == 'fp32x' and cw.cout > 1:
-        # split-operand arithmetic for every GEMM-shaped path (the Cout = 1 mask head is a GEMV on the fp32 VALU)
-        if cw.sp_shift is None or (cw.wu4 is not None and cw.wu4_sp is None):
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError('conv2d: split operands must be built before graph capture (run the stage eagerly once)')
-            if cw.sp_shift is None and cw.wu is not None and cw.wu4 is None and WINO4:
-                cw.wu4 = winograd4_weights(cw.w)          # so that ONE power of two covers every form of this layer
-            cw.ensure_split()
-        d.arith = 1
-        d.w_split = cw.w_sp.data_ptr()
-        d.w_winograd_split = cw.wu_sp.data_ptr() if cw.wu_sp is not None else None
-        d.w_winograd4_split = cw.wu4_sp.data_ptr() if (cw.wu4_sp is not None and d.w_winograd4) else None
-        d.scale = cw.scale_sp.data_ptr()
+    if split and cw.wu4 is not None and cw.wu4_sp is None:          # the F(4x4) operand was built just above
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('conv2d: split operands must be built before graph capture (run the stage eagerly once)')
+        cw.ensure_split()
+        d.w_winograd4_split = cw.wu4_sp.data_ptr()
     d.plan_tile, d.plan_splitk = plan
     if _SPLIT_CHECK and d.arith == 1 and not torch.cuda.is_current_stream_capturing():
         # tools: the same call in fp32 first, then compare (XMEM_SPLIT_CHECK=1; synchronises)
@@ -425,7 +462,9 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
               ('   <-- MISMATCH' if not err < 1e-3 else ''), file=sys.stderr)
     if RECORD is not None:
         RECORD.append(('conv', key, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true,
-                       lambda: lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()), (x, out, res, cw, ws)))
+                       lambda: lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()),
+                       (x, out, res, cw, ws, dict(relu_in=bool(relu_in), relu_out=bool(relu_out), in_ld=ldin, cin=cin, out_ld=out_ld,
+                                                  res_broadcast=bool(res_broadcast)))))
     return out
 
 

@@ -302,11 +302,21 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             msk = vid_reader.resize_mask(msk)
         processor.set_all_labels(list(mapper.remappings.values()))
         a = perf_counter()
-        processor.put_to_permanent_memory(sample.rgb_u8.to(device), msk.to(device))
+        on_device = augment_images_with_masks and not sample.need_resize and config.get('augment_on_device', True)
+        if on_device:
+            # the annotated frame and its 11 'best_all' augmentations: made on the device in one launch, preloaded through ONE
+            # batched key + value pass (the reference runs 12 sequential passes over host-side PIL transforms, :231-242).
+            # With a working-size resize the reference augments BEFORE resizing: that case keeps the host path below.
+            from .augmentations import augment_on_device
+            rgb_dev, msk_dev = sample.rgb_u8.to(device), msk.to(device)
+            aug_rgb, aug_msk = augment_on_device(rgb_dev, msk_dev, subset='best_all')
+            processor.put_many_to_permanent_memory([rgb_dev] + [aug_rgb[i] for i in range(aug_rgb.shape[0])], [msk_dev] + aug_msk)
+        else:
+            processor.put_to_permanent_memory(sample.rgb_u8.to(device), msk.to(device))
         torch.cuda.synchronize()
         preload_time += perf_counter() - a
         loaded = True
-        if augment_images_with_masks:                                # run_on_video.py:231-242, subset 'best_all'
+        if augment_images_with_masks and not on_device:              # run_on_video.py:231-242, subset 'best_all' (host path)
             from .augmentations import get_determenistic_augmentations
             h, w = sample.rgb_u8.shape[:2]
             for img_aug, mask_aug in get_determenistic_augmentations((3, h, w), msk, subset='best_all'):
