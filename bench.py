@@ -387,8 +387,7 @@ def parse_kernel_trace(path):
     busy, last = 0, t0
     for s, e, name in sel:
         k = kern.setdefault(name, [0, 0]); k[0] += 1; k[1] += e - s
-        if family_of(name) == 'affinity':
-            each.setdefault(name, []).append(e - s)
+        each.setdefault(name, []).append(e - s)
         g = fam.setdefault(family_of(name), [0, 0]); g[0] += 1; g[1] += e - s
         a = max(s, last)
         if e > a:

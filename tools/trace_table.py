@@ -14,6 +14,7 @@ w.writerow(['# timed window (marker kernels)', f'{frames} frames', f'{tr["window
 w.writerow(['family', 'launches_per_frame', 'us_per_frame'])
 for f, v in sorted(tr['families'].items(), key=lambda kv: -kv[1][1]):
     w.writerow([f, f'{v[0] / frames:.2f}', f'{v[1] / frames / 1e3:.1f}'])
-w.writerow(['kernel', 'launches_per_frame', 'avg_us', 'us_per_frame', 'share_of_kernel_time'])
+w.writerow(['kernel', 'launches_per_frame', 'avg_us', 'median_us', 'us_per_frame', 'share_of_kernel_time'])
 for k, v in sorted(tr['kernels'].items(), key=lambda kv: -kv[1][1]):
-    w.writerow([k, f'{v[0] / frames:.2f}', f'{v[1] / v[0] / 1e3:.1f}', f'{v[1] / frames / 1e3:.1f}', f'{v[1] / tot:.4f}'])
+    w.writerow([k, f'{v[0] / frames:.2f}', f'{v[1] / v[0] / 1e3:.1f}', f'{tr["median_ns"].get(k, 0.0) / 1e3:.1f}', f'{v[1] / frames / 1e3:.1f}',
+                f'{v[1] / tot:.4f}'])
