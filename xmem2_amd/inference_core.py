@@ -166,13 +166,13 @@ class InferenceCore:
         for t in [image4] + devs:
             t.record_stream(main)
         key, shr, sel, f16, f8, f4 = outs[:6]
-        skip8, skip4 = outs[6]
+        extras = outs[6]                                        # skip8, skip4 [, the decoder fuser's f16 half: conv1@x, downsample@x]
         n = f16.shape[1] * f16.shape[2]
         _, hw, hw_p = packed[0]
         for i, d in enumerate(devs):
             self._pfq.append(dict(ptr=d.data_ptr(), shape=tuple(d.shape), image4=image4[i:i + 1], hw=hw, hw_p=hw_p, pad=pad,
                                   outs=(key[i * n:(i + 1) * n], shr[i * n:(i + 1) * n], sel[i * n:(i + 1) * n],
-                                        f16[i:i + 1], f8[i:i + 1], f4[i:i + 1], (skip8[i:i + 1], skip4[i:i + 1])),
+                                        f16[i:i + 1], f8[i:i + 1], f4[i:i + 1], tuple(t[i:i + 1] for t in extras)),
                                   event=ev, slot=(gid, i), gid=gid, keep=d))
         return devs
 

@@ -52,6 +52,7 @@ class XMem:
         # 272 vs 273 fps), so it is off by default (XMEM_OVERLAP=1 enables it).
         self.overlap_skips = os.environ.get('XMEM_OVERLAP', '0') != '0'
         self.share_x = os.environ.get('XMEM_SHARE_X', '1') != '0'     # several objects: convolve the shared f16 half of the fusers once
+        self.prefuse_x = os.environ.get('XMEM_PREFUSE_X', '1') != '0'  # prefetched frames: the decoder fuser's f16 half in the batched key pass
         self._side = None
         # scratch of the side-stream key-encoder stages is scoped to this instance and released with it
         self._scope = ops.new_scope()
@@ -348,19 +349,20 @@ class XMem:
         W = self._w
         return n_obj > 1 and self.share_x and (p + '.block1.conv1@x') in W and (p + '.block1.downsample@x') in W
 
-    def _fusion(self, cat, p, x=None):
+    def _fusion(self, cat, p, x=None, pre=None):
         """FeatureFusionBlock, model/modules.py:31-41, on the already concatenated [x | g] tensor.  With several objects
         and `x` given ([1,h,w,1024], the shared f16 half of `cat`), block1's two 3x3 convolutions run the x half once
         and only the g half per object (saves 64 % / 80 % of block1's FLOPs for every object but the first)."""
         W = self._w
         b1 = p + '.block1'
-        if x is not None and self._shares_x(p, cat.shape[0]):
+        if x is not None and (pre is not None or self._shares_x(p, cat.shape[0])):
             xd = x.shape[3]
             gpart = cat[..., xd:]
             ld, cg = cat.shape[3], cat.shape[3] - xd
-            sx = ops.conv2d(x, W[b1 + '.conv1@x'], relu_in=True)
+            # pre = (conv1@x(relu(x)), downsample@x(x)) already made in the batched key pass (prefetched frames)
+            sx = pre[0] if pre is not None else ops.conv2d(x, W[b1 + '.conv1@x'], relu_in=True)
             o = ops.conv2d(gpart, W[b1 + '.conv1@g'], relu_in=True, relu_out=True, res=sx, res_broadcast=True, in_ld=ld, cin=cg)
-            dx = ops.conv2d(x, W[b1 + '.downsample@x'])
+            dx = pre[1] if pre is not None else ops.conv2d(x, W[b1 + '.downsample@x'])
             res = ops.conv2d(gpart, W[b1 + '.downsample@g'], res=dx, res_broadcast=True, in_ld=ld, cin=cg)
             g = ops.conv2d(o, W[b1 + '.conv2'], res=res)
         else:
@@ -423,8 +425,14 @@ class XMem:
         ops.conv2d(f16, W['key_proj'], out=proj, out_ld=ld)
         key, shr, sel = ops.key_post(proj, self.key_dim, need_sk, need_ek)
         if inline_skips:                      # same stream: f8 / f4 only depend on the image (model/modules.py:186,231-232)
-            return key, shr, sel, f16, f8, f4, (ops.conv2d(f8, W['decoder.up_16_8.skip_conv']),
-                                                ops.conv2d(f4, W['decoder.up_8_4.skip_conv']))
+            extras = (ops.conv2d(f8, W['decoder.up_16_8.skip_conv']), ops.conv2d(f4, W['decoder.up_8_4.skip_conv']))
+            if self.prefuse_x and ('decoder.fuser.block1.conv1@x') in W and ('decoder.fuser.block1.downsample@x') in W:
+                # FeatureFusionBlock convolves cat([f16, readout, hidden]) (model/modules.py:31-41): W * cat = W_x * f16 + W_g * [readout |
+                # hidden], and the f16 half (1024 of 1600 input channels of block1's two 3x3 convolutions) depends on the frame only -
+                # so it is convolved HERE, in the batched pass on the side stream, and enters the decoder as a residual
+                b1 = 'decoder.fuser.block1'
+                extras += (ops.conv2d(f16, W[b1 + '.conv1@x'], relu_in=True), ops.conv2d(f16, W[b1 + '.downsample@x']))
+            return key, shr, sel, f16, f8, f4, extras
         if overlap:
             main.wait_stream(self._side)                       # join before the stage (and its graph capture) ends
             return key, shr, sel, f16, f8, f4, (skip8, skip4)
@@ -522,7 +530,12 @@ class XMem:
         if h_out and self.hidden_dim > 0:
             c4 = self._w['decoder.pred'].cin
             g4d = self._zero_scratch((K, h, w, _pad4(c4 + 1)), cat16.device)
-        if skips is not None:
+        if skips is not None and len(skips) >= 4:
+            out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot, owner),
+                                  [f16, f8, f4, cat16, hidden, skips[0], skips[1], skips[2], skips[3]],
+                                  lambda a, b, c, d, e, s8, s4, sx, dx: self._segment_eager(a, b, c, d, e, h_out, (s8, s4, sx, dx), g4d),
+                                  alias=(0, 1, 2, 4, 5, 6, 7, 8) if self._is_stage_output(f16) else (4,), mutates=(4,))
+        elif skips is not None:
             out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot, owner),
                                   [f16, f8, f4, cat16, hidden, skips[0], skips[1]],
                                   lambda a, b, c, d, e, s8, s4: self._segment_eager(a, b, c, d, e, h_out, (s8, s4), g4d),
@@ -542,11 +555,12 @@ class XMem:
         W = self._w
         K, h, w, _ = cat16.shape
         hd = self.hidden_dim
-        if not self._shares_x('decoder.fuser', K):
+        pre = (skips[2], skips[3]) if (skips is not None and len(skips) >= 4) else None
+        if pre is None and not self._shares_x('decoder.fuser', K):
             ops.copy_channels(f16, cat16, 0)               # with several objects the f16 half is convolved once (see _fusion)
         if hd > 0:
             ops.copy_channels(hidden, cat16, 1024 + self.value_dim)
-        g16 = self._fusion(cat16, 'decoder.fuser', x=f16)
+        g16 = self._fusion(cat16, 'decoder.fuser', x=f16, pre=pre)
         skip8 = skips[0] if skips is not None else ops.conv2d(f8, W['decoder.up_16_8.skip_conv'])
         g8 = self._group_res(ops.upsample2x_add(g16, skip8), 'decoder.up_16_8.out_conv')
         skip4 = skips[1] if skips is not None else ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])

@@ -412,7 +412,7 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             # a shape the shipped table does not know (another resolution / object count): the 3x3 stride-1 layers still take
             # Winograd with the 64x64 GEMM tile - F(4x4) from 1/8 resolution of 480p up, F(2x2) below - instead of the direct
             # form (deterministic: same shape -> same plan on every machine)
-            plan = (19, 1) if (WINO4 and Ho * Wo >= WINO4_MIN_PIXELS) else (9, 1)
+            plan = (19, 1) if (WINO4 and B * Ho * Wo >= WINO4_MIN_PIXELS) else (9, 1)
         (_tuned_now_x if split else _tuned_now)[key] = plan
     d.w_winograd4 = None
     if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32' \
