@@ -46,6 +46,12 @@ def _list_cap(n):
     return c
 
 
+def _list_stride(n):
+    """Capacity of a list in the SECOND pass (= allocation stride): four times the first pass's, at most 16384."""
+    c = _list_cap(n)
+    return 16384 if c >= 4096 else 4 * c
+
+
 def _make(n, hw, nseg, seed):
     gen = torch.Generator(device='cuda').manual_seed(seed)
     mk = torch.randn(n, 64, generator=gen, device='cuda') * 0.9
@@ -108,12 +114,13 @@ def test_hinted_filter_equals_unhinted_at_served_sizes(n, hw, gw, nseg):
 
 @pytest.mark.parametrize('n,hw,gw,nseg', SIZES, ids=IDS)
 def test_hinted_filter_full_scan_on_exact_ties_at_served_sizes(n, hw, gw, nseg):
-    """More exact duplicates of a query's best match than a candidate list holds: the list overflows in pass 1 AND, with the
-    tightened bound (= the tied value), in pass 2 - flag2 - and the refine evaluates every memory element for that tile.
+    """More exact duplicates of a query's best match than a candidate list holds even in the second pass (whose lists are four
+    times as long): the list overflows in pass 1 AND, with the tightened bound (= the tied value), in pass 2 - flag2 - and the
+    refine evaluates every memory element for that tile.
     The result (lowest indices among the ties, as torch.topk on a stable sort would give) equals the un-hinted call."""
     from xmem2_amd import ops
     mk, ms, qk, qe, cuts = _make(n, hw, nseg, seed=n + 1)
-    lcap = _list_cap(n)
+    lcap = _list_stride(n)
     dup = lcap + 700
     targets = [5, hw // 2 + 3, hw - 2]                                          # three queries in three different 128-query tiles
     for j, q in enumerate(targets):

@@ -1115,7 +1115,7 @@ WsLayout ws_layout(int HW, int n_total) {
     w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
     w.rows16_off = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
     w.gcand32_off = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
-    w.flag_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_cap(n_total) * sizeof(int), 256);
+    w.flag_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_stride(n_total) * sizeof(int), 256);
     w.total = w.flag_off + align_up((size_t)2 * cdiv(HW, AFW_BQ) * sizeof(int), 256);
     return w;
 }
@@ -1240,6 +1240,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
             f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
             f.rows16 = reinterpret_cast<_Float16*>(ws + wl.rows16_off);
             f.tau = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.lcap = aff_filter16_list_cap(base);
+            f.lcap1 = f.lcap; f.lstride = aff_filter16_list_stride(base);
             f.flag1 = h.flag1; f.flag2 = h.flag2; f.only = nullptr; f.flag_out = nullptr;
             f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;
             return aff_filter16_launch(f, stream);

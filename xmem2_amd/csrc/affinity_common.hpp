@@ -79,7 +79,10 @@ struct Filter16Args {
     _Float16* rows16;                // workspace [N + 32][F16_K] for segments whose caller keeps no operand rows (seg[i].rows16 == 0 on entry)
     float* tau;                      // [HW] valid lower bound of the exact k-th similarity (-inf: none yet); raised by the tighten pass
     u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
-    int* gcand32; int* gcnt; int lcap; // [HW][lcap] candidate indices (aff_filter16_list_cap), [HW] zeroed by the bound kernel
+    int* gcand32; int* gcnt;         // [HW][lstride] candidate indices, [HW] list lengths zeroed by the bound kernel
+    int lcap;                        // capacity of a list in THIS pass (pass 1: aff_filter16_list_cap; pass 2: lstride = up to 4x that -
+                                     // after a scene cut the similarities are flat and thousands of pairs sit within eps of the k-th)
+    int lcap1, lstride;              // pass-1 capacity; allocation stride = pass-2 capacity (aff_filter16_list_stride)
     // Two passes.  Pass 1 (only == nullptr) lists every query; a list that overflows (bound too loose: scene cut, first frames,
     // garbage hint) sets flag1 of its 128-query tile.  The tighten launch turns the partial lists of flagged tiles into a real
     // bound (k-th best EXACT similarity of the listed elements), pass 2 (only == flag1) filters and lists those tiles again.
@@ -92,4 +95,5 @@ struct Filter16Args {
 size_t aff_filter16_mask_bytes(int n_total, int HW);
 size_t aff_filter16_rows_bytes(int n_total);
 int aff_filter16_list_cap(int n_total);
+int aff_filter16_list_stride(int n_total);
 int aff_filter16_launch(Filter16Args a, void* stream);            // rows, filter, scan, tighten, filter, scan, refine

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
         else {                                                   // local buffer full: straight to the query's global list
             const int qg = b * 32 + qi;
             const int gs = atomicAdd(&p.gcnt[qg], 1);
-            if (gs < p.lcap) p.gcand32[(size_t)qg * p.lcap + gs] = gi;
+            if (gs < p.lcap) p.gcand32[(size_t)qg * p.lstride + gs] = gi;
             if (gs + 1 >= p.lcap) {                              // a list that reaches its capacity counts as overflowed
                 p.flag_out[qg >> 7] = 1;
                 if (atomicExch(const_cast<int*>(&s_full[qi]), 1) == 0 && atomicAdd(&s_nfull, 1) == 31) s_dead = 1;   // counted once
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     for (int e = tid; e < 32 * SCAN_CAP; e += 256) {
         const int qi = e / SCAN_CAP, j = e - qi * SCAN_CAP, qg = b * 32 + qi;
         if (qg < p.HW && j < min(s_cnt[qi], SCAN_CAP) && s_base[qi] + j < p.lcap)
-            p.gcand32[(size_t)qg * p.lcap + s_base[qi] + j] = s_buf[qi][j];
+            p.gcand32[(size_t)qg * p.lstride + s_base[qi] + j] = s_buf[qi][j];
     }
 }
 
@@ -332,7 +332,9 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
     const int q = blockIdx.x;
     if (TIGHTEN && p.flag1[q >> 7] == 0) return;
     // a list that overflowed even with the tightened bound (thousands of exact ties): every memory element is evaluated
-    const bool full = !TIGHTEN && p.flag2[q >> 7] != 0 && p.gcnt[q] >= p.lcap;
+    // capacity of this query's list: a tile that went through the second pass lists up to lstride entries, the others lcap1
+    const int cap = (!TIGHTEN && p.flag1[q >> 7] != 0) ? p.lstride : p.lcap1;
+    const bool full = !TIGHTEN && p.flag2[q >> 7] != 0 && p.gcnt[q] >= cap;
     float* ne = s_op; float* ke2 = s_op + CK; u64* keys = s_keys[wv];
     if (wv == 0) {
         const float k = p.qk[(size_t)q * CK + lane];
@@ -340,9 +342,9 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
         ne[lane] = -e; ke2[lane] = 2.f * (k * e);
     }
     const float bs = p.qmeta[(size_t)q * 4];          // b_sq with the select kernels' arithmetic (bound kernel)
-    int total = min(p.gcnt[q], p.lcap);
+    int total = min(p.gcnt[q], cap);
     if (full) { total = 0; for (int i = 0; i < p.n_seg; ++i) total += p.seg[i].n; }
-    const int* list = p.gcand32 + (size_t)q * p.lcap;
+    const int* list = p.gcand32 + (size_t)q * p.lstride;
     // the first round's indices are requested without waiting for the count (the list is lcap >= 2048 long; stale entries are
     // never used: every use is guarded by e < total)
     int gi_next = full ? wv * 64 + lane : list[wv * 64 + lane];
@@ -480,6 +482,12 @@ int aff_filter16_list_cap(int n_total) {
     return c;
 }
 
+// allocation stride of the lists = capacity of the SECOND pass: 4x the first pass's, at most 16384
+int aff_filter16_list_stride(int n_total) {
+    const int c = aff_filter16_list_cap(n_total);
+    return c >= 4096 ? 16384 : 4 * c;
+}
+
 size_t aff_filter16_rows_bytes(int n_total) { return ((size_t)n_total + AFF_ROWS) * F16_K * sizeof(_Float16); }
 
 size_t aff_filter16_mask_bytes(int n_total, int HW) {
@@ -535,6 +543,7 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     // pass 2: tiles with an overflowed list, with the bound their partial lists give (these three launches return at once
     // when nothing is flagged - the normal frame)
     a.only = a.flag1; a.flag_out = a.flag2;
+    a.lcap = a.lstride;                                 // the second pass may list up to the allocation stride
     hipLaunchKernelGGL(affinity_refine_kernel<true>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_filter16_kernel<true>, fgrid, dim3(256), 0, s, a);
