@@ -349,67 +349,6 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
     }
 }
 
-// The same for the 3x3 / stride 1 / pad 1 case (the mask head itself): one wave computes EIGHT neighbouring output pixels of a
-// row from the 3 x 10 input pixels under them, so every input row of 1 KiB is fetched 3.75 times instead of 9 (the per-pixel
-// form is bound by those L2 reads: 239 MB for the 480p head).  Lanes over input channels (float4), the nine filter taps of a
-// lane's channels in registers, eight lane-local partial sums, eight wave reductions at the end.
-#define C1_NPX 8
-__global__ __launch_bounds__(256) void conv_cout1_row3x3_kernel(ConvArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int segs = (p.Wo + C1_NPX - 1) / C1_NPX;
-    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wid >= (long)p.B * p.Ho * segs) return;
-    const int seg = (int)(wid % segs);
-    const long row = wid / segs;
-    const int oh = (int)(row % p.Ho), b = (int)(row / p.Ho);
-    const int ow0 = seg * C1_NPX;
-    float acc[C1_NPX];
-#pragma unroll
-    for (int j = 0; j < C1_NPX; ++j) acc[j] = 0.f;
-    for (int c = lane * 4; c < p.Cin; c += 256) {
-        f32x4 wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.Cin + c);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = oh + kh - 1;
-            if ((unsigned)ih >= (unsigned)p.H) continue;
-            const float* xrow = p.in + ((size_t)(b * p.H + ih) * p.W) * p.ldin + c;
-            f32x4 xv[C1_NPX + 2];
-#pragma unroll
-            for (int i = 0; i < C1_NPX + 2; ++i) {                       // all loads of the row segment in flight together
-                const int iw = ow0 - 1 + i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)iw < (unsigned)p.W) v = *reinterpret_cast<const f32x4*>(xrow + (size_t)iw * p.ldin);
-                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                xv[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < C1_NPX + 2; ++i)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int j = i - kw;                                 // output ow0 + j reads input column ow0 + j + kw - 1
-                    if (j < 0 || j >= C1_NPX) continue;
-                    const f32x4 w4 = wt[kh * 3 + kw];
-                    acc[j] = fmaf(xv[i].x, w4.x, acc[j]); acc[j] = fmaf(xv[i].y, w4.y, acc[j]);
-                    acc[j] = fmaf(xv[i].z, w4.z, acc[j]); acc[j] = fmaf(xv[i].w, w4.w, acc[j]);
-                }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < C1_NPX; ++j) acc[j] = wave_sum(acc[j]);
-    if (lane < C1_NPX && ow0 + lane < p.Wo) {
-        float a = acc[0];
-#pragma unroll
-        for (int j = 1; j < C1_NPX; ++j) a = (lane == j) ? acc[j] : a;
-        const size_t m = ((size_t)b * p.Ho + oh) * p.Wo + ow0 + lane;
-        float v = a * p.scale[0] + p.shift[0];
-        if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres];
-        if (p.relu_out) v = fmaxf(v, 0.f);
-        p.out[m * p.ldout] = v;
-    }
-}
-
 // ----------------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions (85 % of the network's FLOPs):
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A      (Lavin & Gray) - 16 multiplies per 2x2 outputs instead of 36.
@@ -1219,12 +1158,10 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (pl.bm == 0) {
-        if (a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1) {
-            const long waves = (long)a.B * a.Ho * cdiv(a.Wo, C1_NPX);
-            hipLaunchKernelGGL(conv_cout1_row3x3_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
-        } else {
-            hipLaunchKernelGGL(conv_cout1_kernel, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
-        }
+        // (a variant with eight output pixels of a row per wave - 3.75 instead of 9 fetches of every input row - measured 28.0 us
+        // against 24.9 us for this one-pixel-per-wave form at the 480p mask head: the kernel is bound by its wave reductions and
+        // load latency, not by the L2 reads; removed)
+        hipLaunchKernelGGL(conv_cout1_kernel, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
         return xmem_check_launch();
     }
     if (pl.bk == 64) rc = pl.generic ? launch_bk<64, true>(pl, a, s) : launch_bk<64, false>(pl, a, s);
