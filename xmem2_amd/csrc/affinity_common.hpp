@@ -73,7 +73,7 @@ struct Filter16Args {
     int n_seg, total_tiles;
     const float* qk; const float* qe;
     int HW, top_k;
-    int splits, tiles_per_split;     // set by aff_filter16_launch
+    int splits, tiles_per_split, qtiles;   // set by aff_filter16_launch (qtiles = query tiles of 128)
     const _Float16* qop16;           // [HW][F16_K] query operand rows          } written by the bound kernel
     const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), 0, 0, 0   }
     _Float16* rows16;                // workspace [N + 32][F16_K] for segments whose caller keeps no operand rows (seg[i].rows16 == 0 on entry)

@@ -25,15 +25,19 @@
 #include "affinity_common.hpp"
 #include <stdlib.h>
 
-#define F16_BQ 128             // queries per filter workgroup (4 blocks of 32)
-#define F16_WAVES 4
+#define F16_BQ 128             // queries per FLAG tile (flag1 / flag2 / `only`: 4 blocks of 32)
+// filter workgroup of NW waves (4 | 8): 64 NW queries (2 blocks of 32 per wave), LDS stages of NW 32-row tiles
+// (2 stages x NW x 32 x 304 B = 76 | 152 KB; 9 pieces of 16 bytes per thread and stage either way)
 #ifndef F16_WG_PER_CU
 #define F16_WG_PER_CU 2       // filter workgroups (4 waves) per CU the register budget is set for
 #endif
 #ifndef RF_WAVES
 #define RF_WAVES 4           // waves of a refine workgroup (one query)
 #endif
-#define F16_LDB 304            // bytes per query operand row in LDS (288 + 16: odd multiple of 16 B)
+#ifndef F16_PF
+#define F16_PF 2               // k-steps the row fragments are requested from LDS ahead of their MFMAs
+#endif
+#define F16_LDB 304            // bytes per memory operand row in LDS (288 + 16: odd multiple of 16 B, conflict-free 16-byte fragment reads)
 
 // the exact similarity of ONE (row, query) pair: the fmaf chain of the fp32 MFMA select (affinity_wide_kernel):
 // accumulator starts at -b_sq; per 8-channel group t and j = 0..3: k-pairs (8t+j, 8t+4+j) of [x^2 * -e] then of [x * 2ke].
@@ -103,124 +107,218 @@ __global__ __launch_bounds__(256) void affinity_rows16_kernel(const float* __res
 }
 
 // ============================================================ filter ===================================================
-// grid (query tiles of 128, splits of the memory), 4 waves; wave w of split s takes tiles t_begin + w, + 4, ...
-// Per 32-row tile and 32-query block: 9 x v_mfma_f32_32x32x16_f16 give the UPPER estimates directly (augmented operands),
-// then 16 compares against tau whose lane masks ARE the output words.
-// PASS2 = the second pass over the flagged query tiles (its own kernel name: a trace tells the working launch from the one that
-// normally returns at once)
-template <bool PASS2>
-__global__ __launch_bounds__(256, F16_WG_PER_CU) void affinity_filter16_kernel(Filter16Args p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Bh[F16_BQ * F16_LDB];
-    __shared__ float s_tau[F16_BQ];
+// C[rows x queries] = rows16 . qop16^T on v_mfma_f32_32x32x16_f16, K = 144; the output is ONE BIT per pair (estimate >= tau).
+// Workgroup = NW waves (4 | 8), 64 NW queries x one split of the memory's 32-row tiles:
+//   queries  wave w owns query blocks 2w, 2w + 1 (32 queries each); their operand rows stay in REGISTERS for the whole
+//            workgroup (2 x 9 fragments = 72 VGPRs, read from qop16 once)
+//   rows     streamed through LDS in stages of NW tiles by all threads: consecutive lanes copy consecutive 16-byte pieces of
+//            consecutive 288-byte rows - whole cache lines, 9 pieces per thread and stage, one address add per piece on the
+//            regular stage (one segment, no clamped row); double buffered, one barrier per stage; every wave reads every
+//            tile's fragments from LDS (ds_read_b128, row stride 304 B: conflict-free), two k-steps ahead of their MFMAs
+//   per wave and PAIR of tiles: 9 k-steps x (2 row fragments from LDS, 4 MFMAs: 2 tiles x 2 query blocks), then 16 compares
+//            per lane and (tile, query block) against tau, collected in the lane's own halfword of the bit matrix.
+// Round 2 kept 128 queries in LDS and loaded the rows as MFMA fragments straight from global memory (one lane per row:
+// 32 cache lines per load instruction, every row crossing L2 -> CU once per 128 queries): 972 us at 921 600 x 3 600,
+// 9.56 ms at 4 177 920 x 8 160.  This layout: 864 us / 8.15 ms (8 waves), 37 us (was 40) at 51 840 x 1 620.  Counters at
+// 921 600 x 3 600: matrix pipe busy 0.47 of the kernel's cycles at 2.2 GHz, VALU busy about the same, a third of the wave
+// cycles waiting - the two waves of a SIMD cover only part of each other's address / compare / barrier phases.
+// 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 (round-robin dispatch); all query tiles of one split - the workgroups
+// that stream the SAME rows - share L % 8 and neighbouring slots.
+// PASS2 = the second pass over the flagged 128-query tiles (its own kernel name: a trace tells the working launch from the one
+// that normally returns at once)
+template <bool PASS2, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity_filter16_kernel(Filter16Args p) {
+    constexpr int F16_STAGE = NW, F16_WGQ = 64 * NW, NTHR = 64 * NW;
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][F16_STAGE * AFF_ROWS * F16_LDB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
-    if (PASS2 && p.only[blockIdx.x] == 0) return;               // pass 2: flagged query tiles only
-    const int q0 = blockIdx.x * F16_BQ;
-    const int split = blockIdx.y;
+    const int slot = blockIdx.x >> 3;
+    const int qtile = slot % p.qtiles;
+    const int split = (blockIdx.x & 7) + 8 * (slot / p.qtiles);
+    if (split >= p.splits) return;
+    const int b0 = qtile * (F16_WGQ / 32) + wave * 2;            // this wave's first query block
+    bool active = b0 * 32 < p.HW;                                // (wave-uniform)
+    if (PASS2) {                                                 // pass 2: flagged 128-query tiles only
+        const int nflag = (p.HW + F16_BQ - 1) / F16_BQ, f = (F16_WGQ / F16_BQ) * qtile;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < F16_WGQ / F16_BQ; ++i) any = any || (f + i < nflag && p.only[f + i] != 0);
+        if (!any) return;
+        if (active) active = p.only[b0 >> 2] != 0;
+    }
 
-    // query operands: 128 rows of 288 B prepared once per call by the bound kernel (coalesced 16-B copies)
-    for (int e = tid; e < F16_BQ * 18; e += 256) {
-        const int q = e / 18, part = e - q * 18, qg = q0 + q;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (qg < p.HW) v = *reinterpret_cast<const uint4*>(p.qop16 + (size_t)qg * F16_K + part * 8);
-        *reinterpret_cast<uint4*>(Bh + q * F16_LDB + part * 16) = v;
-    }
-    if (tid < F16_BQ) {
-        const int qg = q0 + tid;
+    h16x8 bq[2][9];
+    float my_tau[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (b0 + i) * 32 + l31;
+        const bool ok = active && q < p.HW;
+        const _Float16* src = p.qop16 + (size_t)min(q, p.HW - 1) * F16_K + lh * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            h16x8 v = *reinterpret_cast<const h16x8*>(src + 16 * t);
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+            }
+            bq[i][t] = v;
+        }
         // a query without a bound (-inf) keeps every pair: its list fills up, flags the tile, and the tighten pass makes a bound
-        s_tau[tid] = qg < p.HW ? p.tau[qg] : INFINITY;
+        my_tau[i] = ok ? p.tau[q] : INFINITY;
     }
-    __syncthreads();
 
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
+    const int nst = (t_end - t_begin + F16_STAGE - 1) / F16_STAGE;
 
-    // a tile's operand rows (lane: row l31, halfs [16t + 8 lh, +8) for t = 0..8), row index clamped into the segment
+    // one stage = F16_STAGE tiles x 32 rows x 18 pieces of 16 bytes = 9 pieces per thread.  Row index clamped into the segment
     // (the duplicated rows of a segment's last tile set spurious bits; the scan drops rows past the segment's end)
-    auto issue_loads = [&](int tile, h16x8 (&dst)[9]) {
-        if (tile >= t_end) return;
-        int sg = 0;
-#pragma unroll
-        for (int i = 1; i < XMEM_MAX_SEGMENTS; ++i)
-            if (i < p.n_seg && tile >= p.seg[i].tile0) sg = i;
-        const int r = min((tile - p.seg[sg].tile0) * AFF_ROWS + l31, p.seg[sg].n - 1);
-        const _Float16* src = p.seg[sg].rows16 + (size_t)r * F16_K + lh * 8;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) dst[t] = *reinterpret_cast<const h16x8*>(src + 16 * t);
-    };
-
-    float my_tau[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) my_tau[i] = s_tau[i * 32 + l31];
-    const size_t blk0 = (size_t)blockIdx.x * 4;
-
-    // one tile: 36 MFMAs in k-step order (four independent accumulator chains), the query fragments of step t + 1 requested
-    // from LDS before the MFMAs of step t; then the compares.  The LDS offset is made opaque per tile: the fragments are loop
-    // invariant and the compiler would otherwise keep all 144 registers of them resident (and spill).
-    auto do_tile = [&](int tile, const h16x8 (&a)[9]) {
-        int boff = l31 * F16_LDB + lh * 16;
-        asm volatile("" : "+v"(boff));
-        const unsigned char* bq = Bh + boff;
-        f32x16 c[4];
-        h16x8 bc[4], bn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bc[i] = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB);
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            if (t < 8) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bn[i] = *reinterpret_cast<const h16x8*>(bq + i * 32 * F16_LDB + (t + 1) * 32);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (t == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bc[i], z, 0, 0, 0);
-                } else {
-                    c[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], bc[i], c[i], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bc[i] = bn[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int mlo = 0, mhi = 0;                                   // lane r < 16 collects word r
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // NaN-safe "upper estimate >= tau": a non-finite estimate keeps the pair for the exact pass
-                const u64 m = __ballot(!(c[i][r] < my_tau[i]));
-                // gfx950: a VALU write of an SGPR needs 2 wait states before a VALU read of it; the compiler cannot see into the asm
-                asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                    : "+v"(mlo), "+v"(mhi) : "s"((int)(unsigned)m), "s"((int)(unsigned)(m >> 32)), "n"(r));
-            }
-            if (lane < 16)
-                p.mask[((blk0 + i) * (size_t)p.total_tiles + tile) * 16 + lane] = ((u64)(unsigned)mhi << 32) | (u64)(unsigned)mlo;
-        }
-    };
-
-    // two tiles of operand rows in flight per wave
-    h16x8 a0[9], a1[9];
-    int tile = t_begin + wave;
-    issue_loads(tile, a0);
-    issue_loads(tile + F16_WAVES, a1);
-    while (tile < t_end) {
-        do_tile(tile, a0);
-        issue_loads(tile + 2 * F16_WAVES, a0);
-        tile += F16_WAVES;
-        if (tile >= t_end) break;
-        do_tile(tile, a1);
-        issue_loads(tile + 2 * F16_WAVES, a1);
-        tile += F16_WAVES;
+    // (the segment table is copied to scalars once: read from the kernel arguments inside the loop it cost a scalar load and a
+    // wait per piece; tiles past the split's end repeat its last tile - branch-free loads, nobody reads those slots)
+    static_assert(XMEM_MAX_SEGMENTS == 4, "segment select below is written out for 4 segments");
+    const int gt1 = 1 < p.n_seg ? p.seg[1].tile0 : 0x7fffffff, gt2 = 2 < p.n_seg ? p.seg[2].tile0 : 0x7fffffff,
+              gt3 = 3 < p.n_seg ? p.seg[3].tile0 : 0x7fffffff;
+    const int gn0 = p.seg[0].n, gn1 = 1 < p.n_seg ? p.seg[1].n : 1, gn2 = 2 < p.n_seg ? p.seg[2].n : 1, gn3 = 3 < p.n_seg ? p.seg[3].n : 1;
+    const _Float16 *gr0 = p.seg[0].rows16, *gr1 = 1 < p.n_seg ? p.seg[1].rows16 : gr0, *gr2 = 2 < p.n_seg ? p.seg[2].rows16 : gr0,
+                   *gr3 = 3 < p.n_seg ? p.seg[3].rows16 : gr0;
+    const int gt0 = p.seg[0].tile0;
+    uint4 st0, st1, st2, st3, st4, st5, st6, st7, st8;
+    // FAST stage (the rule; decided per stage with scalar arithmetic): its tiles lie in one segment, none is the segment's
+    // clamped last tile and none is past the split - the stage is F16_STAGE x 9216 contiguous bytes, piece e at byte 16 e
+    const unsigned char* fbase = nullptr;
+    bool ffast = false;
+#define F16_STAGE_SETUP(S)                                                                                           \
+    {                                                                                                                \
+        const int T0 = t_begin + (S) * F16_STAGE, Tl = T0 + F16_STAGE - 1;                                           \
+        const bool s1 = T0 >= gt1, s2 = T0 >= gt2, s3 = T0 >= gt3;                                                   \
+        const _Float16* base = s3 ? gr3 : s2 ? gr2 : s1 ? gr1 : gr0;                                                 \
+        const int tile0 = s3 ? gt3 : s2 ? gt2 : s1 ? gt1 : gt0, n = s3 ? gn3 : s2 ? gn2 : s1 ? gn1 : gn0;            \
+        const int next0 = s3 ? 0x7fffffff : s2 ? gt3 : s1 ? gt2 : gt1;                                               \
+        ffast = Tl < t_end && Tl < next0 && (Tl - tile0 + 1) * AFF_ROWS <= n;                                        \
+        fbase = reinterpret_cast<const unsigned char*>(base) + (size_t)(T0 - tile0) * (AFF_ROWS * F16_K * 2);        \
     }
+#define F16_FETCH_ONE(J, DST)                                                                                        \
+    if (ffast) {                                                                                                     \
+        DST = *reinterpret_cast<const uint4*>(fbase + (size_t)(tido + NTHR * (J)) * 16);                             \
+    } else {                                                                                                         \
+        const int e = tido + NTHR * (J), rr = e / 18, part = e - rr * 18;                                              \
+        const int tile = min(t_begin + fs * F16_STAGE + (rr >> 5), t_end - 1);                                       \
+        const bool s1 = tile >= gt1, s2 = tile >= gt2, s3 = tile >= gt3;                                             \
+        const _Float16* base = s3 ? gr3 : s2 ? gr2 : s1 ? gr1 : gr0;                                                 \
+        const int tile0 = s3 ? gt3 : s2 ? gt2 : s1 ? gt1 : gt0, n = s3 ? gn3 : s2 ? gn2 : s1 ? gn1 : gn0;            \
+        const int r = min((tile - tile0) * AFF_ROWS + (rr & 31), n - 1);                                             \
+        DST = *reinterpret_cast<const uint4*>(base + (size_t)r * F16_K + part * 8);                                  \
+    }
+#define F16_FETCH(S)                                                                                                 \
+    {                                                                                                                \
+        const int fs = (S);                                                                                          \
+        F16_STAGE_SETUP(fs)                                                                                          \
+        F16_FETCH_ONE(0, st0) F16_FETCH_ONE(1, st1) F16_FETCH_ONE(2, st2) F16_FETCH_ONE(3, st3) F16_FETCH_ONE(4, st4) \
+        F16_FETCH_ONE(5, st5) F16_FETCH_ONE(6, st6) F16_FETCH_ONE(7, st7) F16_FETCH_ONE(8, st8)                      \
+    }
+#define F16_STASH_ONE(J, SRC)                                                                                        \
+    {                                                                                                                \
+        const int e = tido + NTHR * (J), rr = e / 18, part = e - rr * 18;                                              \
+        *reinterpret_cast<uint4*>(sb + rr * F16_LDB + part * 16) = SRC;                                                 \
+    }
+#define F16_STASH(B)                                                                                                 \
+    {                                                                                                                \
+        unsigned char* sb = (B);                                                                                       \
+        F16_STASH_ONE(0, st0) F16_STASH_ONE(1, st1) F16_STASH_ONE(2, st2) F16_STASH_ONE(3, st3) F16_STASH_ONE(4, st4) \
+        F16_STASH_ONE(5, st5) F16_STASH_ONE(6, st6) F16_STASH_ONE(7, st7) F16_STASH_ONE(8, st8)                      \
+    }
+
+    // a pair of tiles of the current stage: 36 MFMAs (four independent accumulator chains), the row fragments of step t + 1
+    // requested from LDS before the MFMAs of step t; then the compares
+    // (Fetching piece t and storing it inside the k-steps of the pairs - address arithmetic and LDS stores under the MFMAs
+    // instead of in blocks of their own - was measured 12 % SLOWER at 921 600 x 3 600: extra issue slots between MFMAs cost
+    // more than the blocks do.)
+    // (the pair body is written into the stage loop - `PAIR BODY` - rather than a lambda: as a lambda with a call site in a
+    // loop its captured variables stayed in scratch memory)
+    int tido = tid;                                   // (made opaque once per stage: the per-piece row / part numbers are
+                                                      // recomputed instead of living in 18 registers across the loop)
+    F16_FETCH(0)
+    F16_STASH(&Ah[0][0])
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        // (the last stage fetches its own tiles again instead of branching around the loads: the staging registers stay
+        // plain registers for the compiler)
+        asm volatile("" : "+v"(tido));
+        F16_FETCH(min(s + 1, nst - 1))
+        if (active) {
+            const int tile = t_begin + s * F16_STAGE;
+#pragma nounroll
+            for (int g = 0; g < F16_STAGE; g += 2) {
+                const int nt = min(2, t_end - (tile + g));
+                if (nt <= 0) break;
+                const unsigned char* A = &Ah[s & 1][g * AFF_ROWS * F16_LDB];
+                const int tl = tile + g;
+                // ---- PAIR BODY
+                const unsigned char* ar = A + l31 * F16_LDB + lh * 16;
+                f32x16 c[2][2];
+                h16x8 fr[9][2];                                              // (constant indices after unrolling: three steps live)
+#pragma unroll
+                for (int t = 0; t < F16_PF; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) fr[t][u] = *reinterpret_cast<const h16x8*>(ar + u * AFF_ROWS * F16_LDB + t * 32);
+                // (the nine k-steps are written out: with the piece selected by a switch on the loop counter the compiler kept
+                // every fragment array in scratch memory)
+#define F16_KSTEP(T)                                                                                                  \
+                {                                                                                                             \
+                    if ((T) + F16_PF < 9) {                                                                                   \
+                        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                         \
+                            fr[((T) + F16_PF) % 9][u] = *reinterpret_cast<const h16x8*>(ar + u * AFF_ROWS * F16_LDB + ((T) + F16_PF) * 32); \
+                    }                                                                                                         \
+                    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                             \
+                        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+                            if ((T) == 0) {                                                                                   \
+                                f32x16 z;                                                                                     \
+                                _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.f;                                    \
+                                c[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0][u], bq[i][0], z, 0, 0, 0);             \
+                            } else {                                                                                          \
+                                c[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[T][u], bq[i][T], c[u][i], 0, 0, 0);       \
+                            }                                                                                                 \
+                        }                                                                                                     \
+                    __builtin_amdgcn_sched_barrier(0);                                                                        \
+                }
+                F16_KSTEP(0) F16_KSTEP(1) F16_KSTEP(2) F16_KSTEP(3) F16_KSTEP(4) F16_KSTEP(5) F16_KSTEP(6) F16_KSTEP(7) F16_KSTEP(8)
+#undef F16_KSTEP
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u >= nt) break;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        // 16 compares per lane, collected as 16 bits of the lane's own halfword: bits = 2 bits + (estimate >= tau) by
+                        // v_cmp + add-with-carry (two VALU instructions per pair, no SGPR round trip; r = 0 ends up in bit 15).
+                        // NaN-safe "upper estimate >= tau": v_cmp_nlt is true for a non-finite estimate - the exact pass decides
+                        // (r = 0 in plain C: the compiler's hazard recognizer places the MFMA-result -> VALU wait states, which it
+                        // cannot do for operands it only sees inside an asm statement)
+                        unsigned bits = !(c[u][i][0] < my_tau[i]) ? 1u : 0u;
+#pragma unroll
+                        for (int r = 1; r < 16; ++r)
+                            asm("v_cmp_nlt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+                                : "+v"(bits) : "v"(c[u][i][r]), "v"(my_tau[i]) : "vcc");
+                        if ((b0 + i) * 32 < p.HW)
+                            reinterpret_cast<unsigned short*>(p.mask)[(((size_t)(b0 + i) * p.total_tiles + tl + u) << 6) + lane] = (unsigned short)bits;
+                    }
+                }
+                // ---- end of PAIR BODY
+            }
+        }
+        F16_STASH(&Ah[(s + 1) & 1][0])
+        __syncthreads();
+    }
+#undef F16_FETCH
+#undef F16_STAGE_SETUP
+#undef F16_FETCH_ONE
+#undef F16_STASH
+#undef F16_STASH_ONE
 }
 
 // ============================================================ scan =====================================================
-// bit (word r, lane j) of tile t, query block b  <->  query 32 b + (j & 31), row 32 (t - tile0) + (r & 3) + 8 (r >> 2) + 4 (j >> 5)
+// per (query block b, tile t): 64 halfwords, one per filter lane; bit 15 - r of lane l's halfword  <->  query 32 b + (l & 31),
+// row 32 (t - tile0) + (r & 3) + 8 (r >> 2) + 4 (l >> 5).  Read as 16 words of 64 bits: word k holds lanes 4k .. 4k + 3.
 #define SCAN_TILES 128
 #define SCAN_CAP 192
 template <bool PASS2>
@@ -249,11 +347,12 @@ __global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
     const u64* words = p.mask + ((size_t)b * p.total_tiles + t0) * 16;
     const int lane = tid & 63;
     auto insert = [&](int w, int j) {                            // bit j of word w (relative to this slice)
-        const int qi = j & 31;
+        const int fl = 4 * (w & 15) + (j >> 4), r = 15 - (j & 15);  // filter lane, accumulator register
+        const int qi = fl & 31;
         if (s_full[qi]) return;
-        const int tile = t0 + (w >> 4), r = w & 15;
+        const int tile = t0 + (w >> 4);
         const SegDev sd = seg_of_tile(p, tile);
-        const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (j >> 5);
+        const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (fl >> 5);
         if (row >= sd.n) return;                                 // clamped duplicate of the segment's last row
         const int gi = sd.base + row;
         const int slot = atomicAdd(&s_cnt[qi], 1);
@@ -514,15 +613,23 @@ extern "C" int xmem_affinity_rows16(const float* key, const float* shrinkage, in
 
 int aff_filter16_launch(Filter16Args a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int qt = cdiv(a.HW, F16_BQ);
-    // two 4-wave workgroups per CU: splits so that query tiles x splits ~ 512, >= 4 tiles per wave
-    int sp = (256 * F16_WG_PER_CU) / qt; if (sp < 1) sp = 1;
-    { int maxs = a.total_tiles / (4 * F16_WAVES); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
-    a.tiles_per_split = cdiv(a.total_tiles, sp);
+    // 8-wave workgroups (512 queries, one per CU) when the query count fills them and the memory is long enough: the rows
+    // cross the fabric once per 512 instead of once per 256 queries
+    int nw = (a.HW >= 2048 && a.total_tiles >= 8192) ? 8 : 4;
+    if (const char* e = getenv("XMEM_F16_WAVES")) nw = atoi(e) == 8 ? 8 : 4;   // tools: A/B
+    const int wgq = 64 * nw, stage = nw, per_xcd = nw == 4 ? 32 * F16_WG_PER_CU : 32;
+    const int qt = cdiv(a.HW, wgq), qf = cdiv(a.HW, F16_BQ);
+    // all workgroups of a split resident on one XCD at once when the query tiles allow: 8 x floor(per_xcd / query tiles) splits,
+    // whole LDS stages, >= 2 stages per split
+    int sp = 8 * (per_xcd / qt); if (sp < 8) sp = 8;
+    if (const char* e = getenv("XMEM_F16_SPLITS")) sp = atoi(e);   // tools: A/B of the split count
+    { int maxs = a.total_tiles / (2 * stage); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
+    a.tiles_per_split = cdiv(cdiv(a.total_tiles, sp), stage) * stage;
     a.splits = cdiv(a.total_tiles, a.tiles_per_split);
     int n_total = 0;
     for (int i = 0; i < a.n_seg; ++i) n_total += a.seg[i].n;
-    const dim3 fgrid(qt, a.splits), sgrid(qt * 4, cdiv(a.total_tiles, SCAN_TILES));
+    a.qtiles = qt;
+    const dim3 fgrid(8 * qt * cdiv(a.splits, 8)), sgrid(qf * 4, cdiv(a.total_tiles, SCAN_TILES));
     int rc;
     // operand rows: kept by the caller (xmem_key_segment.rows16), else derived into the workspace for this call
     for (int i = 0; i < a.n_seg; ++i) {
@@ -535,7 +642,8 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     // pass 1: every tile, the caller's bound
     a.only = nullptr; a.flag_out = a.flag1;
     if (g_prof_ev[0]) (void)hipEventRecord(g_prof_ev[0], s);       // tools: bracket the pass-1 filter (xmem_affinity_profile_events)
-    hipLaunchKernelGGL(affinity_filter16_kernel<false>, fgrid, dim3(256), 0, s, a);
+    if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<false, 8>), fgrid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((affinity_filter16_kernel<false, 4>), fgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     if (g_prof_ev[1]) (void)hipEventRecord(g_prof_ev[1], s);
     hipLaunchKernelGGL(affinity_scan_kernel<false>, sgrid, dim3(256), 0, s, a);
@@ -546,7 +654,8 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     a.lcap = a.lstride;                                 // the second pass may list up to the allocation stride
     hipLaunchKernelGGL(affinity_refine_kernel<true>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_filter16_kernel<true>, fgrid, dim3(256), 0, s, a);
+    if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<true, 8>), fgrid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((affinity_filter16_kernel<true, 4>), fgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_scan_kernel<true>, sgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
