@@ -657,8 +657,8 @@ def main():
         calls_pf = (aff['calls'] / nf) if aff else 1.0
         gf_per_call = aff_gf / max(calls_pf, 1e-9)
         filt_tflops = (gf_per_call / fe['avg_ms']) if fe else None            # algorithmic F_sim of one call / the filter kernel's own time
-        q_pad = (alg['hw'] + 127) // 128 * 128
-        exec_gf = gf_per_call * (F16_K / 128.0) * (q_pad / alg['hw'])           # what the kernel really contracts: K = 144, queries padded to 128
+        q_pad = (alg['hw'] + 63) // 64 * 64                                     # a wave contracts two 32-query blocks or none
+        exec_gf = gf_per_call * (F16_K / 128.0) * (q_pad / alg['hw'])           # what the kernel really contracts: K = 144, queries padded to 64
         line = {
             'metric': (BASELINE_METRIC if args.workload == 'b32' else f'frames/sec ({wl["desc"]})') + PRECISION_LABEL[args.precision],
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -672,14 +672,14 @@ def main():
                        'control_plane': backend or 'none'},
             'per_rank_fps': per_rank,
             'roofline': {'bound': 'mfma',
-                         'kernel': 'affinity_filter16_kernel<false> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
+                         'kernel': 'affinity_filter16_kernel<false, 4|8> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
                                    'of model/memory_util.py:7-39 on v_mfma_f32_32x32x16_f16 with augmented fp16 operands (the result is a rigorous '
                                    'UPPER estimate; one candidate bit per memory row x query).  Around it in the same call: bound from the previous '
                                    'frame\'s matches, scan of the bit matrix, [tighten + second filter / scan pass over query tiles whose lists '
                                    'overflowed], exact fp32 refine of the listed candidates - outputs bit-identical to the fp32 MFMA select',
                          'note': 'achieved = SURVEY 8(d) algorithmic FLOPs of the similarity (F_sim = 4*C_k*N*HW per call) / the average duration of '
                                  'THIS kernel; peak = the dense fp16 MFMA peak, the pipe it runs on; frac = executed fraction of that pipe in algorithmic '
-                                 'FLOPs (executed_tflops counts the K = 144 operands and the queries padded to 128).  frac_fp32_equivalent is the round-2 '
+                                 'FLOPs (executed_tflops counts the K = 144 operands and the queries padded to 64).  frac_fp32_equivalent is the round-2 '
                                  'yardstick: F_sim / the time of the WHOLE call (all kernels) / the fp32 MFMA peak the contraction ran on before - it '
                                  'exceeds 1 on large memories because the work is not done in fp32 any more',
                          'achieved': filt_tflops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -745,8 +745,8 @@ def main():
                         if family_of(k) == 'affinity' and v[0]:
                             ks[k.split('(')[0]] = dict(launches_per_frame=v[0] / st, avg_us=v[1] / v[0] / 1e3, us_per_frame=v[1] / st / 1e3,
                                                        median_us=tr['median_ns'].get(k, 0.0) / 1e3)
-                    # the pass-1 filter is its own instantiation (<false>): its executed fp16 FLOPs / its own time, from the trace
-                    fk = next((k for k in ks if 'filter16' in k and ('<false>' in k or 'ILb0' in k)), None)
+                    # the pass-1 filter is its own instantiation (<false, waves>): its executed fp16 FLOPs / its own time, from the trace
+                    fk = next((k for k in ks if 'filter16' in k and ('<false' in k or 'ILb0' in k)), None)
                     if fk and ks[fk]['avg_us']:
                         tf = exec_gf / (ks[fk]['avg_us'] * 1e-3)
                         ks[fk].update(executed_gflop_per_launch=exec_gf, executed_tflops=tf, peak_tflops=PEAK_F16_MFMA_TFLOPS,

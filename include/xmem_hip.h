@@ -300,6 +300,10 @@ int xmem_gather_rows(const float* src, int C, const int32_t* index, int n, float
  * similarity[:, -count:], memory_util.py:55-60); entries before are zeroed. */
 int xmem_softmax_rows_suffix(float* sim, int P, int n, int count, void* stream);
 
+/* in-place top-k softmax of each row of sim [P][n], zeros elsewhere (do_softmax with top_k, memory_util.py:41-54: topk, exp
+ * without max shift, / sum, scatter into zeros) on a materialised similarity; exact ties at the k-th value -> lowest indices. */
+int xmem_softmax_rows_topk(float* sim, int P, int n, int k, void* stream);
+
 /* out[p][c] = sum_i aff[p][n - count + i] * V[i][c], i < count: prototype values / shrinkage
  * (memory_manager.py:382-388).  V [count][C]. out [P][C]. */
 int xmem_weighted_rows(const float* aff, int P, int n, int count, const float* V, int C, float* out, void* stream);

@@ -152,3 +152,33 @@ def test_read_memory_and_memory_util_dense_forms(hip_net):
     aff_r, usage_r = R.do_softmax(sim_ref.clone(), top_k=10, return_usage=True)
     torch.testing.assert_close(aff.cpu(), aff_r, rtol=2e-3, atol=1e-6)
     torch.testing.assert_close(usage.cpu(), usage_r, rtol=2e-3, atol=1e-6)
+
+
+def test_do_softmax_topk_rows_kernel_vs_oracle():
+    """do_softmax(top_k) on a materialised similarity (memory_util.py:41-54) through xmem_softmax_rows_topk: random rows against
+    the oracle, k = 1, k = n, and exact ties at the k-th value (a stable sort's choice: the lowest indices)."""
+    from xmem2_amd import memory_util as MU, ops
+    g = torch.Generator().manual_seed(11)
+    sim = torch.randn(2, 5000, 37, generator=g) * 3                      # B x N x HW
+    for k in (1, 30, 64):
+        aff, usage = MU.do_softmax(sim.cuda(), top_k=k, return_usage=True)
+        aff_r, usage_r = R.do_softmax(sim.clone(), top_k=k, return_usage=True)
+        assert torch.equal(aff.cpu() != 0, aff_r != 0), f'k={k}: different elements kept'
+        torch.testing.assert_close(aff.cpu(), aff_r, rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(usage.cpu(), usage_r, rtol=1e-5, atol=1e-8)
+        assert int((aff != 0).sum(1).min()) == int((aff != 0).sum(1).max()) == k
+    small = torch.randn(1, 7, 5, generator=g)
+    full = MU.do_softmax(small.cuda(), top_k=7)                          # k = n: the un-shifted softmax over everything
+    torch.testing.assert_close(full.cpu(), small.exp() / small.exp().sum(1, keepdim=True), rtol=1e-5, atol=1e-8)
+    rows = torch.full((3, 300), -2.0)
+    rows[:, 17] = 4.0; rows[:, 250] = 3.0                                # two clear winners, 298 elements tied for the rest
+    rows[1, 100:140] = 0.5                                               # row 1: 40 ties at the k-th value, 8 of them kept
+    out = ops.softmax_rows_topk(rows.cuda().clone(), 10).cpu()
+    for r in range(3):
+        kept = torch.nonzero(out[r]).flatten().tolist()
+        want = [17, 250] + (list(range(100, 108)) if r == 1 else [i for i in range(300) if i not in (17, 250)][:8])
+        assert sorted(kept) == sorted(want), f'row {r}: kept {kept}'
+        e = rows[r, kept].exp()
+        torch.testing.assert_close(out[r, kept], e / e.sum(), rtol=1e-5, atol=1e-8)
+    with pytest.raises(RuntimeError):
+        ops.softmax_rows_topk(rows.cuda(), 301)

@@ -16,3 +16,7 @@ timeout 600 python bench.py --precision fp32x --keep-trace $OUT/split > $OUT/${R
 python tools/trace_table.py $OUT/split/b32_kernel_trace.csv > $OUT/${R}_bench_b32_split_timed_region_per_frame.csv 2>> $OUT/stats.err
 rm -f $OUT/b32_kernel_trace.csv $OUT/split/b32_kernel_trace.csv
 ls -la $OUT
+# the large-memory workloads (their readout is dominated by the filter kernel)
+timeout 600 python bench.py --workload c4 --steps 100 --trace-steps 30 > $OUT/${R}_bench_c4.json 2> $OUT/bench_c4.err
+timeout 900 python bench.py --workload c5 --steps 40 --no-kernel-trace --plain-steps 0 > $OUT/${R}_bench_c5.json 2> $OUT/bench_c5.err
+ls -la $OUT

@@ -90,6 +90,7 @@ _SIGS = {
     'xmem_topk_1d': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'xmem_gather_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'xmem_softmax_rows_suffix': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'xmem_softmax_rows_topk': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'xmem_weighted_rows': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'xmem_select_greater': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'xmem_selector_prepare': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

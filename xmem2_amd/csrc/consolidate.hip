@@ -107,6 +107,68 @@ extern "C" int xmem_softmax_rows_suffix(float* sim, int P, int n, int count, voi
     return xmem_check_launch();
 }
 
+// top-k softmax of each row in place, zeros elsewhere (do_softmax with top_k on a materialised similarity, memory_util.py:41-54:
+// topk -> exp WITHOUT max shift -> / sum -> scatter into zeros).  One workgroup per row: the k-th largest value by bitwise
+// descent over order-preserving integer keys (32 counting passes over the row, L2 resident), exact ties at the threshold go to
+// the lowest indices (a stable sort's choice), then exp / sum / scale.
+__device__ __forceinline__ unsigned order_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // NaN sorts above +inf, as torch.topk ranks it
+}
+__global__ __launch_bounds__(256) void softmax_rows_topk_kernel(float* __restrict__ sim, int n, int k) {
+    __shared__ int s_cnt[4];
+    __shared__ float s_sum[4];
+    float* row = sim + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto count_if = [&](auto pred) -> int {                     // number of row elements whose key satisfies pred (uniform result)
+        int c = 0;
+        for (int i = tid; i < n; i += 256) c += pred(order_key(row[i])) ? 1 : 0;
+        c = wave_sum_i(c);
+        __syncthreads();
+        if (lane == 0) s_cnt[wv] = c;
+        __syncthreads();
+        return (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+    };
+    unsigned thr = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = thr | (1u << bit);
+        if (count_if([=](unsigned key) { return key >= cand; }) >= k) thr = cand;
+    }
+    const int cg = count_if([=](unsigned key) { return key > thr; });
+    const int need = k - cg;                                    // >= 1 of the elements tied at the threshold
+    // exp of the kept elements in place (0 elsewhere) and their sum; ties are ranked in index order, chunk by chunk
+    float acc = 0.f;
+    int seen = 0;                                               // ties in earlier chunks (uniform)
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const float v = i < n ? row[i] : 0.f;
+        const unsigned key = i < n ? order_key(v) : 0u;
+        const bool tie = i < n && key == thr;
+        const unsigned long long m = __ballot(tie);
+        __syncthreads();
+        if (lane == 0) s_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int before = seen + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wv; ++w) before += s_cnt[w];
+        seen += (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        const bool keep = i < n && (key > thr || (tie && before < need));
+        const float e = keep ? expf(v) : 0.f;
+        if (i < n) row[i] = e;
+        acc += e;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s_sum[wv] = acc;
+    __syncthreads();
+    const float total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+    for (int i = tid; i < n; i += 256) row[i] = row[i] / total;
+}
+
+extern "C" int xmem_softmax_rows_topk(float* sim, int P, int n, int k, void* stream) {
+    if (!sim || P <= 0 || n <= 0 || k <= 0 || k > n) return XMEM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(softmax_rows_topk_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, sim, n, k);
+    return xmem_check_launch();
+}
+
 // out[p][c] = sum_i aff[p][n-count+i] * V[i][c];  block: 64 channels x 4 row stripes, 8 prototypes per block
 #define WR_P 8
 __global__ void weighted_rows_kernel(const float* __restrict__ aff, int P, int n, int count, const float* __restrict__ V, int C,

@@ -4,7 +4,7 @@
 The inference path never materialises the N x HW affinity (MemoryManager.match_memory_rows -> xmem_affinity_topk +
 xmem_readout_sparse); these functions are the dense, full-softmax form the reference uses at training time
 (`XMem.read_memory`, model/network.py:89-105) and in the long-term consolidation, built from the same C entry points
-(xmem_similarity_dense, xmem_softmax_rows_suffix, xmem_weighted_rows, xmem_affinity_topk).  They do materialise B x N x HW.
+(xmem_similarity_dense, xmem_softmax_rows_suffix, xmem_softmax_rows_topk, xmem_weighted_rows).  They do materialise B x N x HW.
 """
 import torch
 
@@ -30,16 +30,13 @@ def do_softmax(similarity, top_k=None, inplace=False, return_usage=False):
     """memory_util.py:41-65 on a materialised B x N x HW similarity: top-k softmax without max shift, or the stable full
     softmax over the memory axis.  (`inplace` is accepted for signature compatibility; a new tensor is returned.)"""
     B, N, HW = similarity.shape
-    if top_k is not None:
-        values, indices = torch.topk(similarity, k=top_k, dim=1)                         # plumbing on a materialised matrix
-        x_exp = values.exp()
-        x_exp = x_exp / torch.sum(x_exp, dim=1, keepdim=True)
-        affinity = torch.zeros_like(similarity).scatter_(1, indices, x_exp)
-    else:
-        rows = similarity.transpose(1, 2).contiguous()                                   # [B, HW, N]: softmax over each row
-        for b in range(B):
+    rows = similarity.transpose(1, 2).contiguous()                                       # [B, HW, N]: softmax over each row
+    for b in range(B):
+        if top_k is not None:
+            ops.softmax_rows_topk(rows[b], top_k)                                        # xmem_softmax_rows_topk
+        else:
             ops.softmax_rows_suffix(rows[b], N)
-        affinity = rows.transpose(1, 2)
+    affinity = rows.transpose(1, 2)
     if return_usage:
         return affinity, affinity.sum(dim=2)
     return affinity

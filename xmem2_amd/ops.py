@@ -804,6 +804,16 @@ def softmax_rows_suffix(sim, count):
     return sim
 
 
+def softmax_rows_topk(sim, k):
+    """In place on contiguous rows [P, n]: softmax over each row's k largest entries (no max shift, memory_util.py:45-54),
+    zeros elsewhere."""
+    P, n = sim.shape
+    if not sim.is_contiguous():
+        raise RuntimeError('softmax_rows_topk: rows must be contiguous')
+    check(load().xmem_softmax_rows_topk(ptr(_req(sim, 'sim')), P, n, k, stream_ptr()))
+    return sim
+
+
 def weighted_rows(aff, count, V):
     """aff [P,n]; V [count,C] -> [P,C] using the last `count` columns of aff."""
     P, n = aff.shape
