@@ -303,3 +303,32 @@ def test_library_has_no_packed_fp32_valu_instructions(tmp_path):
         assert not packed, f'{src}: {len(packed)} packed-f32 VALU instructions in the device code (build without -packed-fp32-ops?)'
         total_mfma += len(re.findall(r'\bv_mfma_', asm))
     assert total_mfma > 1000
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
+    """Register arrays that the compiler fails to keep in registers end up in scratch (private) memory - it happened twice while
+    the filter kernel was re-laid out in round 3 (staging registers written under a condition; a lambda naming an LDS array)
+    and costs 2x and more.  The code objects' kernel metadata must report a private segment of 0 bytes for EVERY kernel."""
+    import re
+    import subprocess
+    from xmem2_amd import build as B
+    llvm = '/opt/rocm/lib/llvm/bin'
+    tools = [os.path.join(llvm, t) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip('ROCm LLVM binutils not installed')
+    B.build(force=False, verbose=False)
+    n_kernels = 0
+    for src in B.SOURCES:
+        obj = os.path.join(B.CSRC, src.replace('.hip', '.o'))
+        fat, co = str(tmp_path / 'fat.bin'), str(tmp_path / 'dev.co')
+        subprocess.run([tools[0], '-O', 'binary', '--only-section=.hip_fatbin', obj, fat], check=True)
+        subprocess.run([tools[1], '--unbundle', '--type=o', f'--input={fat}', f'--targets=hipv4-amdgcn-amd-amdhsa--{B.ARCH}',
+                        f'--output={co}'], check=True)
+        notes = subprocess.run([tools[2], '--notes', co], check=True, capture_output=True, text=True).stdout
+        names = re.findall(r'\.name:\s+(\S+)', notes)
+        priv = [int(v) for v in re.findall(r'\.private_segment_fixed_size:\s+(\d+)', notes)]
+        assert names and len(names) == len(priv), f'{src}: kernel metadata not found'
+        bad = [(n, p) for n, p in zip(names, priv) if p != 0]
+        assert not bad, f'{src}: kernels with scratch memory (bytes per lane): {bad}'
+        n_kernels += len(names)
+    assert n_kernels > 100
