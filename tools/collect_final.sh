@@ -15,8 +15,10 @@ cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_b
 timeout 600 python bench.py --precision fp32x --keep-trace $OUT/split > $OUT/${R}_bench_b32_split.json 2> $OUT/bench_split.err
 python tools/trace_table.py $OUT/split/b32_kernel_trace.csv > $OUT/${R}_bench_b32_split_timed_region_per_frame.csv 2>> $OUT/stats.err
 rm -f $OUT/b32_kernel_trace.csv $OUT/split/b32_kernel_trace.csv
-ls -la $OUT
 # the large-memory workloads (their readout is dominated by the filter kernel)
 timeout 600 python bench.py --workload c4 --steps 100 --trace-steps 30 > $OUT/${R}_bench_c4.json 2> $OUT/bench_c4.err
 timeout 900 python bench.py --workload c5 --steps 40 --no-kernel-trace --plain-steps 0 > $OUT/${R}_bench_c5.json 2> $OUT/bench_c5.err
+for wl in c3 b32motion; do
+  timeout 900 python bench.py --workload $wl --steps 100 --trace-steps 30 --cpu-frames 6 > $OUT/${R}_bench_$wl.json 2> $OUT/bench_$wl.err
+done
 ls -la $OUT
