@@ -622,7 +622,7 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     // all workgroups of a split resident on one XCD at once when the query tiles allow: 8 x floor(per_xcd / query tiles) splits,
     // whole LDS stages, >= 2 stages per split
     int sp = 8 * (per_xcd / qt); if (sp < 8) sp = 8;
-    if (const char* e = getenv("XMEM_F16_SPLITS")) sp = atoi(e);   // tools: A/B of the split count
+    if (const char* e = getenv("XMEM_F16_SPLITS")) { sp = atoi(e); if (sp < 1) sp = 1; }   // tools: A/B of the split count
     { int maxs = a.total_tiles / (2 * stage); if (maxs < 1) maxs = 1; if (sp > maxs) sp = maxs; }
     a.tiles_per_split = cdiv(cdiv(a.total_tiles, sp), stage) * stage;
     a.splits = cdiv(a.total_tiles, a.tiles_per_split);
