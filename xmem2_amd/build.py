@@ -50,6 +50,9 @@ def source_digest():
     with open(os.path.join(os.path.dirname(CSRC), '..', 'include', 'xmem_hip.h'), 'rb') as fh:
         h.update(fh.read())
     h.update(' '.join(DEVICE_FLAGS).encode())
+    for src in sorted(EXTRA_FLAGS):
+        h.update((src + ':' + ' '.join(EXTRA_FLAGS[src])).encode())
+    h.update(os.environ.get('XMEM_HIPCC_FLAGS', '').encode())
     return h.hexdigest()[:16]
 
 
