@@ -315,50 +315,55 @@ def test_run_on_video_with_augmented_permanent_memory(tmp_path, hip_net):
     assert bool(torch.isfinite(p).all()) and float((p.sum(0) - 1).abs().max()) < 1e-4
 
 
+def _noise_floor_gate(name, gpu, floor, frac_cap, floor_factor=1.5):
+    """The GPU path against oracle(1 thread) may deviate by what north_star allows (IoU >= 0.999 per object) or, where the
+    reference's OWN thread-count noise on the same frames is larger, by `floor_factor` (1.5) x that measured floor - never more.
+    `floor` = oracle(8 threads) vs oracle(1 thread), `gpu` = HIP path vs oracle(1 thread), both from clip_util.compare."""
+    for k, (g, f) in enumerate(zip(gpu['iou'], floor['iou'])):
+        allowed = max(1e-3, floor_factor * (1.0 - f))
+        assert 1.0 - g <= allowed, (f'{name}: object {k + 1} IoU {g:.5f} vs oracle(1 thread); the oracle\'s own 8-vs-1-thread IoU on the '
+                                    f'same frames is {f:.5f}: allowed deficit {allowed:.2e}')
+    cap = max(frac_cap, floor_factor * floor['mismatch'] / max(floor['pixels'], 1))
+    assert gpu['mismatch'] / max(gpu['pixels'], 1) <= cap, f"{name}: argmax mismatch {gpu['mismatch']}/{gpu['pixels']} > {cap:.2e}"
+
+
 def test_e2e_480p_three_objects_consolidation_vs_oracle(hip_net, ref_net):
     """BASELINE config 3 at its stated size: 480p, 3 objects, a long-term consolidation inside the clip (mem_every=2,
-    T_max=4 -> compress_features fires at the 5th temporary frame), batched key hints - against the oracle frame by frame."""
-    from conftest import base_config
-    from xmem2_amd.inference_core import InferenceCore
-    from xmem2_amd import ops
-    from xmem2_amd.synth import synthetic_frames, synthetic_masks
-    t, hw, K = 13, (480, 854), 3
-    cfg = base_config(mem_every=2, max_mid_term_frames=4, min_mid_term_frames=2, num_prototypes=64)
-    frames = T(synthetic_frames(t, *hw)); masks = T(synthetic_masks(t, K, *hw))
-    core, ref = InferenceCore(hip_net, cfg), R.RefCore(ref_net, cfg)
-    for c in (core, ref):
-        c.set_all_labels([1, 2, 3])
-    core.put_to_permanent_memory(frames[0].cuda(), masks[0].cuda())
-    ref.put_to_permanent_memory(frames[0], masks[0])
-    dev = [frames[i].cuda() for i in range(t)]
-    inter, uni = np.zeros((2, K)), np.zeros((2, K))              # [before | after the first consolidation]
-    mism, first_lt = [0, 0], None
-    for i in range(1, t):
-        if (i - 1) % 4 == 0:
-            core.prefetch_keys(dev[i:i + 4])
-        p = core.step(dev[i], None, None, end=(i == t - 1))
-        q = ref.step(frames[i], None, None, end=(i == t - 1))
-        a, b = ops.argmax_u8(p).cpu().numpy(), torch.argmax(q, 0).numpy().astype(np.uint8)
-        ph = 0 if first_lt is None else 1
-        mism[ph] += int((a != b).sum())
-        for k in range(K):
-            inter[ph, k] += ((a == k + 1) & (b == k + 1)).sum(); uni[ph, k] += ((a == k + 1) | (b == k + 1)).sum()
-        assert float((p.cpu() - q).abs().mean()) < (5e-4 if ph == 0 else 2e-3), f'frame {i}'
-        m, rm = core.memory, ref.memory
-        assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == \
-               (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size), f'frame {i}'
-        if first_lt is None and m.long_mem.size > 0:
-            first_lt = i
-    assert first_lt is not None and first_lt < t - 2, 'the clip must include a consolidation with frames after it'
-    n_before, n_after = (first_lt) * hw[0] * hw[1], (t - 1 - first_lt) * hw[0] * hw[1]
-    iou_b, iou_a = inter[0] / np.maximum(uni[0], 1), inter[1] / np.maximum(uni[1], 1)
-    print(f'480p x 3 objects: consolidation at frame {first_lt}; before: IoU {iou_b}, mismatch {mism[0]}/{n_before}; '
-          f'after: IoU {iou_a}, mismatch {mism[1]}/{n_after}')
-    # Every second frame is written back to the memory with its PREDICTED masks (mem_every=2), so round-off feeds back and
-    # the two small rectangle objects (a few thousand pixels) lose ~0.1 % IoU to boundary pixels at zero margin - the same
-    # size as the reference's own 8-thread vs 1-thread noise (DESIGN.md section 3).  The consolidation then picks its
-    # prototypes by a top-k over accumulated usage (memory_manager.py:355): 1-ulp differences can fork that discrete choice
-    # (SURVEY 7.3), after which the memories differ legitimately.  Gates: as the multi-group clip above (mismatch < 5e-4,
-    # mean |dp| < 5e-4) before the consolidation, 2x that after it; IoU >= 0.997 per object throughout.
-    assert iou_b.min() >= 0.997 and mism[0] / n_before < 5e-4
-    assert iou_a.min() >= 0.997 and mism[1] / n_after < 1e-3
+    T_max=4 -> compress_features fires at the 5th temporary frame), batched key hints - against the oracle frame by frame,
+    WITH the oracle's own thread-count noise measured on the same frames: north_star's IoU >= 0.999 is the gate wherever the
+    reference itself (8 threads vs 1 thread) stays above it; where it does not, the gate is twice the
+    measured floor and the floor is printed."""
+    import clip_util as U
+    clip = U.c3_clip()
+    o1, p1, s1 = U.run_oracle(ref_net, clip, 1)
+    o8, p8, s8 = U.run_oracle(ref_net, clip, 8)
+    a, p, s = U.run_gpu(hip_net, clip)
+    assert s == s1, 'memory sizes differ from the oracle'
+    first_lt = next((i for i, z in enumerate(s) if z[2] > 0), None)
+    assert first_lt is not None and first_lt < len(a) - 2, 'the clip must include a consolidation with frames after it'
+    for i in range(len(a)):
+        assert float((p[i] - p1[i]).abs().mean()) < (5e-4 if i < first_lt else 2e-3), f'frame {i + 1}'
+    for ph, (lo, hi) in enumerate([(0, first_lt), (first_lt, len(a))]):
+        gpu, floor = U.compare(a, o1, clip.labels, lo, hi), U.compare(o8, o1, clip.labels, lo, hi)
+        tag = f'480p x 3 objects, {"before" if ph == 0 else "after"} the consolidation (frame {first_lt + 1})'
+        print(f'{tag}:\n   HIP    vs oracle(1 thr): {U.fmt(gpu)}\n   oracle(8 thr) vs (1 thr): {U.fmt(floor)}')
+        # Every second frame is written back to the memory with its PREDICTED masks (mem_every=2), so round-off feeds back;
+        # the consolidation picks prototypes by a top-k over accumulated usage (memory_manager.py:355): 1-ulp differences can
+        # fork that discrete choice (SURVEY 7.3) - for the 8-thread oracle exactly as for the GPU.
+        _noise_floor_gate(tag, gpu, floor, frac_cap=(1e-4 if ph == 0 else 2e-4))
+
+
+def test_e2e_240p_two_objects_noise_floor(hip_net, ref_net):
+    """The 240p two-object golden clip (object 1 is ~1800 px) with the reference's own noise floor next to it: oracle at 8
+    threads vs the 1-thread goldens on the same frames, then the HIP path under the same gate as config 3."""
+    import clip_util as U
+    clip = U.golden_clip('240p_2obj', (240, 427), 2)
+    g = load_golden('e2e_240p_2obj')
+    o1, _, s1 = U.run_oracle(ref_net, clip, 1)
+    assert all(np.array_equal(x, y) for x, y in zip(o1, g['argmax'])), 'oracle(1 thread) must reproduce the reference-recorded goldens'
+    o8, _, _ = U.run_oracle(ref_net, clip, 8)
+    a, _, s = U.run_gpu(hip_net, clip)
+    assert s == s1
+    gpu, floor = U.compare(a, o1, clip.labels), U.compare(o8, o1, clip.labels)
+    print(f'240p x 2 objects:\n   HIP    vs oracle(1 thr): {U.fmt(gpu)}\n   oracle(8 thr) vs (1 thr): {U.fmt(floor)}')
+    _noise_floor_gate('240p x 2 objects', gpu, floor, frac_cap=1e-4)

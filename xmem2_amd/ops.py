@@ -224,6 +224,9 @@ def winograd4_weights(w):
 # that the 36 tile-position GEMMs are too small to fill the chip.  XMEM_WINO4=0 turns it off (F(2x2) everywhere).
 WINO4_MIN_PIXELS = int(os.environ.get('XMEM_WINO4_MIN_PIXELS', '4096'))   # applies to F(2x2) entries of the plan table only
 WINO4 = os.environ.get('XMEM_WINO4', '1') != '0'
+# Tools knob (parity attribution, tools/parity_by_plan.py): 'direct' runs every convolution in the direct implicit-GEMM form,
+# 'f2' replaces F(4x4) by F(2x2); None / '' = the shipped plan table.  Read at call time so that a tool can switch it.
+CONV_FORM = os.environ.get('XMEM_CONV_FORM') or None
 
 
 def winograd_weights(w):
@@ -402,6 +405,8 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         d.w_winograd_split = cw.wu_sp.data_ptr() if cw.wu_sp is not None else None
         d.w_winograd4_split = cw.wu4_sp.data_ptr() if cw.wu4_sp is not None else None    # taken only by an F(4x4) plan
         d.scale = cw.scale_sp.data_ptr()
+    if plan is None and CONV_FORM == 'direct' and _PRECISION == 'fp32':
+        plan, explicit = (0, 0), True            # the library's deterministic direct-form heuristic
     if plan is None:
         plan = _lookup_plan(key, split)
     if plan is None:
@@ -412,10 +417,10 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             # a shape the shipped table does not know (another resolution / object count): the 3x3 stride-1 layers still take
             # Winograd with the 64x64 GEMM tile - F(4x4) from 1/8 resolution of 480p up, F(2x2) below - instead of the direct
             # form (deterministic: same shape -> same plan on every machine)
-            plan = (19, 1) if (WINO4 and B * Ho * Wo >= WINO4_MIN_PIXELS) else (9, 1)
+            plan = (19, 1) if (WINO4 and CONV_FORM != 'f2' and B * Ho * Wo >= WINO4_MIN_PIXELS) else (9, 1)
         (_tuned_now_x if split else _tuned_now)[key] = plan
     d.w_winograd4 = None
-    if not explicit and 7 <= plan[0] <= 12 and WINO4 and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32' \
+    if not explicit and 7 <= plan[0] <= 12 and WINO4 and CONV_FORM != 'f2' and cw.wu is not None and Ho * Wo >= WINO4_MIN_PIXELS and _PRECISION == 'fp32' \
             and '__tuned_with_f4__' not in _load_plans():      # a table tuned against F(4x4) already says which layers take it
         if cw.wu4 is None:
             if torch.cuda.is_current_stream_capturing():
@@ -423,7 +428,7 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             cw.wu4 = winograd4_weights(cw.w)
         d.w_winograd4 = cw.wu4.data_ptr()
         plan = (plan[0] + 10, plan[1])
-    elif 17 <= plan[0] <= 22 and not WINO4 and not explicit:
+    elif 17 <= plan[0] <= 22 and (not WINO4 or CONV_FORM == 'f2') and not explicit:
         plan = (plan[0] - 10, plan[1])               # XMEM_WINO4=0: the same GEMM tile under F(2x2)
     elif 17 <= plan[0] <= 22:
         if cw.wu4 is None and cw.wu is not None:
