@@ -57,19 +57,19 @@ int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& job : jobs) {
-        int B, H, W, Cin, Cout;
-        if (sscanf(job.first.c_str(), "%d %d %d %d %d", &B, &H, &W, &Cin, &Cout) != 5) { fprintf(stderr, "bad shape '%s'\n", job.first.c_str()); return 1; }
-        const size_t npix = (size_t)B * H * W;
-        std::vector<float> x(npix * Cin), w((size_t)Cout * 9 * Cin), sc(Cout), sh(Cout), res(npix * Cout);
+        int B, H, W, Cin, Cout, KS = 3, stride = 1;
+        if (sscanf(job.first.c_str(), "%d %d %d %d %d %d %d", &B, &H, &W, &Cin, &Cout, &KS, &stride) < 5) { fprintf(stderr, "bad shape '%s'\n", job.first.c_str()); return 1; }
+        const int pad = KS / 2, Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
+        const size_t npix_in = (size_t)B * H * W, npix = (size_t)B * Ho * Wo;
+        std::vector<float> x(npix_in * Cin), w((size_t)Cout * KS * KS * Cin), sc(Cout), sh(Cout), res(npix * Cout);
         for (auto& v : x) v = urand();
-        const float ws = 1.f / sqrtf(9.f * Cin);
+        const float ws = 1.f / sqrtf((float)(KS * KS) * Cin);
         for (auto& v : w) v = urand() * ws * 1.7f;
         for (auto& v : sc) v = 1.f + 0.25f * urand();
         for (auto& v : sh) v = 0.1f * urand();
         for (auto& v : res) v = urand();
-        std::vector<float> u2, u4;
-        winograd_weights(w, Cout, Cin, G2, 4, u2);
-        winograd_weights(w, Cout, Cin, G4, 6, u4);
+        std::vector<float> u2(4, 0.f), u4(4, 0.f);
+        if (KS == 3 && stride == 1) { winograd_weights(w, Cout, Cin, G2, 4, u2); winograd_weights(w, Cout, Cin, G4, 6, u4); }
         float *dx, *dw, *dsc, *dsh, *dres, *du2, *du4, *dout, *dref;
         CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&dw, w.size() * 4)); CK(hipMalloc(&dsc, Cout * 4)); CK(hipMalloc(&dsh, Cout * 4));
         CK(hipMalloc(&dres, res.size() * 4)); CK(hipMalloc(&du2, u2.size() * 4)); CK(hipMalloc(&du4, u4.size() * 4));
@@ -80,10 +80,10 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(du2, u2.data(), u2.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(du4, u4.data(), u4.size() * 4, hipMemcpyHostToDevice));
         xmem_conv_desc d; memset(&d, 0, sizeof d);
         d.in = dx; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.ldin = Cin;
-        d.w = dw; d.Cout = Cout; d.KH = 3; d.KW = 3; d.stride = 1; d.pad = 1;
+        d.w = dw; d.Cout = Cout; d.KH = KS; d.KW = KS; d.stride = stride; d.pad = pad;
         d.scale = dsc; d.shift = dsh; d.res = use_res ? dres : nullptr; d.ldres = Cout; d.ldout = Cout;
         d.relu_in = relu_in; d.relu_out = relu_out; d.plan_splitk = 1;
-        d.w_winograd = du2; d.w_winograd4 = du4;
+        if (KS == 3 && stride == 1) { d.w_winograd = du2; d.w_winograd4 = du4; }
         std::vector<float> yref(npix * Cout), y(npix * Cout);
         auto run = [&](int plan, float* out, int n) -> float {
             d.plan_tile = plan; d.out = out;
@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
         run(ref_plan, dref, 1);
         CK(hipMemcpy(yref.data(), dref, yref.size() * 4, hipMemcpyDeviceToHost));
         double amax = 0; for (float v : yref) amax = std::max(amax, (double)fabsf(v));
-        const double gflop = 2.0 * npix * Cout * 9.0 * Cin * 1e-9;
+        const double gflop = 2.0 * npix * Cout * (double)(KS * KS) * Cin * 1e-9;
         char* plans = strdup(job.second.c_str());
         for (char* tok = strtok(plans, ","); tok; tok = strtok(nullptr, ",")) {
             const int plan = atoi(tok);
@@ -115,9 +115,9 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(y.data(), dout, y.size() * 4, hipMemcpyDeviceToHost));
             double err = 0; size_t bad = 0;
             for (size_t i = 0; i < y.size(); ++i) { const double e = fabs((double)y[i] - yref[i]); if (!(e <= 1e30)) ++bad; else err = std::max(err, e); }
-            const double div = plan >= 17 ? 4.0 : (plan >= 7 ? 2.25 : 1.0);
+            const double div = (plan >= 35 || KS != 3) ? 1.0 : ((plan >= 17 && plan <= 28) ? 4.0 : (plan >= 7 ? 2.25 : 1.0));
             printf("shape %-22s r%d%d%d plan %2d  %8.1f us  %7.1f TF direct-form  %6.1f TF executed  err %.2e%s\n", job.first.c_str(), relu_in, use_res, relu_out,
-                   plan, us, gflop / us * 1e-3, gflop / div / us * 1e-3, err / amax, bad ? "  NON-FINITE OUTPUT" : "");
+                   plan, us, gflop / us * 1e3, gflop / div / us * 1e3, err / amax, bad ? "  NON-FINITE OUTPUT" : "");
             fflush(stdout);
         }
         free(plans);

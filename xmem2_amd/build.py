@@ -9,8 +9,8 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-SOURCES = ['conv_mfma.hip', 'elementwise.hip', 'affinity.hip', 'affinity_filter.hip', 'consolidate.hip', 'selector.hip', 'augment.hip']
-HEADERS = ['common.hpp', 'affinity_common.hpp']
+SOURCES = ['conv_mfma.hip', 'gemm_stream.hip', 'elementwise.hip', 'affinity.hip', 'affinity_filter.hip', 'consolidate.hip', 'selector.hip', 'augment.hip']
+HEADERS = ['common.hpp', 'affinity_common.hpp', 'gemm_stream.hpp']
 LIB = os.path.join(CSRC, 'libxmem_hip.so')
 ARCH = 'gfx950'
 EXTRA_FLAGS = {'augment.hip': ['-ffp-contract=off']}      # per-source flags: the augmentation kernel rounds where the host libraries round

@@ -13,6 +13,7 @@
 //
 // Replaces the nn.Conv2d/BatchNorm2d/ReLU/residual call sites listed in include/xmem_hip.h.
 #include "common.hpp"
+#include "gemm_stream.hpp"
 #include <stdlib.h>
 
 // BK (k-depth of a staged tile) is a template parameter: 32 or 64.  LDS rows are padded by 4 floats:
@@ -888,7 +889,8 @@ __global__ __launch_bounds__(256) void wino_gemm_f16_kernel(WinoF16Args p) {
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; bool wino4; bool split; };
+struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; bool wino4; bool split;
+              int stream, sv, sring; };      // stream: 1 = GEMM on the streaming kernel (csrc/gemm_stream.hip), tile variant sv, ring sring
 
 inline bool wino_ok(const xmem_conv_desc* d) {
     return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
@@ -902,7 +904,7 @@ int validate(const xmem_conv_desc* d) {
     if (d->Cin % 4 != 0 || d->ldin % 4 != 0 || d->ldin < d->Cin || d->ldout < d->Cout) return XMEM_ERR_UNSUPPORTED;
     if (d->res && d->ldres < d->Cout) return XMEM_ERR_BAD_ARG;
     if ((d->H + 2 * d->pad - d->KH) < 0 || (d->W + 2 * d->pad - d->KW) < 0) return XMEM_ERR_BAD_ARG;
-    if (d->plan_tile < 0 || d->plan_tile > 22 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
+    if (d->plan_tile < 0 || d->plan_tile > 40 || d->plan_splitk < 0) return XMEM_ERR_BAD_ARG;
     return XMEM_OK;
 }
 
@@ -922,6 +924,7 @@ Plan make_plan(const xmem_conv_desc* d) {
     pl.fused = 0;
     pl.f16 = false;
     pl.wino4 = false;
+    pl.stream = 0; pl.sv = 0; pl.sring = 3;
     // split-operand arithmetic ('fp32x', opt-in): every GEMM-shaped path; the Cout = 1 GEMV stays fp32 (it is HBM-bound)
     pl.split = d->arith == 1 && d->w_split != nullptr;
     if (d->Cout == 1) { pl.split = false; pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
@@ -929,6 +932,19 @@ Plan make_plan(const xmem_conv_desc* d) {
     if (d->plan_tile > 0) {
         static const int cfg[6][3] = {{128, 128, 32}, {128, 64, 32}, {64, 64, 32}, {128, 128, 64}, {128, 64, 64}, {64, 64, 64}};
         int t = d->plan_tile;
+        if (t >= 23) {
+            // 23..28: F(4x4) with the position GEMMs on the streaming kernel, 29..34: F(2x2) likewise, 35..40: the pointwise
+            // (1x1, pad 0) convolution itself on it; within a group: tile {64x64, 128x64, 128x128} x ring {3, 4} stages.
+            // Shapes the streaming kernel does not take (split arithmetic, Cin % 32 != 0, 1x1 with padding) fall back to the
+            // 64x64 tile of the corresponding classic plan.
+            const int grp = (t - 23) / 6, v = (t - 23) % 6;
+            const bool ok = !pl.split && d->Cin % 32 == 0 &&
+                            (grp == 2 ? (d->KH == 1 && d->KW == 1 && d->pad == 0 &&
+                                         (double)d->B * d->H * d->W * d->ldin * 4.0 < 2.0e9 && (double)d->Cout * d->Cin * 4.0 < 2.0e9)
+                                      : (wino_ok(d) && (grp == 0 ? d->w_winograd4 != nullptr : true)));
+            if (ok) { pl.stream = 1; pl.sv = v % 3; pl.sring = 3 + v / 3; }
+            t = grp == 0 ? 19 : (grp == 1 ? 9 : 3);
+        }
         if (t >= 17) {                     // F(4x4, 3x3) with the GEMM tile of plan t - 10; F(2x2) when its operand is absent
             if (wino_ok(d) && (pl.split ? d->w_winograd4_split : (const void*)d->w_winograd4)) pl.wino4 = true;
             t -= 10;
@@ -974,9 +990,21 @@ Plan make_plan(const xmem_conv_desc* d) {
             if (pl.splitk < 1) pl.splitk = 1;
         }
     }
+    if (pl.stream) pl.splitk = 1;                  // the streaming kernel contracts the whole K of a unit
     pl.kt_per_split = cdiv(pl.nk, pl.splitk);
     pl.splitk = cdiv(pl.nk, pl.kt_per_split);
     return pl;
+}
+
+// the Winograd-domain position GEMMs M[xi] = V[xi] U[xi]^T on the streaming kernel: G positions of [P x Cin] x [Cin x Cout]
+int launch_stream_positions(const Plan& pl, const float* V, const float* U, float* Mt, int G, int P, int Cin, int Cout, hipStream_t s) {
+    GemmStreamArgs g = {};
+    g.A = V; g.B = U; g.C = Mt;
+    g.a_gstride = (long)P * Cin; g.b_gstride = (long)Cout * Cin; g.c_gstride = (long)P * Cout;
+    g.M = P; g.N = Cout; g.K = Cin; g.G = G;
+    g.lda = Cin; g.ldb = Cin; g.ldc = Cout;
+    g.mode = 0; g.stride = 1;
+    return gemm_stream_launch(g, pl.sv, pl.sring, s);
 }
 
 // the 1x1 fast path needs 32-bit byte offsets into both operands (per group)
@@ -1065,6 +1093,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         g.relu_in = 0; g.relu_out = 0; g.nk = pl.nk; g.splitk = 1; g.kt_per_split = pl.nk;
         g.tiles_m = cdiv(g.M, pl.bm); g.tiles_n = cdiv(g.Cout, pl.bn);
         g.raw = 1; g.in_gstride = (long)P * d->Cin; g.w_gstride = (long)d->Cout * d->Cin; g.out_gstride = (long)P * d->Cout;
+        if (pl.stream) rc = launch_stream_positions(pl, V, d->w_winograd4, Mt, 36, (int)P, d->Cin, d->Cout, s);
+        else
         rc = (pl.bk == 64) ? (pl.generic ? launch_bk<64, true>(pl, g, s, 36) : launch_bk<64, false>(pl, g, s, 36))
                            : (pl.generic ? launch_bk<32, true>(pl, g, s, 36) : launch_bk<32, false>(pl, g, s, 36));
         if (rc != XMEM_OK) return rc;
@@ -1143,6 +1173,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         g.relu_in = 0; g.relu_out = 0; g.nk = pl.nk; g.splitk = 1; g.kt_per_split = pl.nk;
         g.tiles_m = cdiv(g.M, pl.bm); g.tiles_n = cdiv(g.Cout, pl.bn);
         g.raw = 1; g.in_gstride = (long)P * d->Cin; g.w_gstride = (long)d->Cout * d->Cin; g.out_gstride = (long)P * d->Cout;
+        if (pl.stream) rc = launch_stream_positions(pl, V, d->w_winograd, Mt, 16, (int)P, d->Cin, d->Cout, s);
+        else
         rc = (pl.bk == 64) ? (pl.generic ? launch_bk<64, true>(pl, g, s, 16) : launch_bk<64, false>(pl, g, s, 16))
                            : (pl.generic ? launch_bk<32, true>(pl, g, s, 16) : launch_bk<32, false>(pl, g, s, 16));
         if (rc != XMEM_OK) return rc;
@@ -1157,6 +1189,15 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         if (!workspace || workspace_bytes < need) return XMEM_ERR_WORKSPACE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (pl.stream && pl.bm != 0) {                 // pointwise convolution on the streaming kernel, fused epilogue
+        GemmStreamArgs g = {};
+        g.A = d->in; g.B = d->w; g.C = d->out; g.scale = d->scale; g.shift = d->shift; g.res = d->res;
+        g.M = a.M; g.N = d->Cout; g.K = d->Cin; g.G = 1;
+        g.lda = d->ldin; g.ldb = d->Cin; g.ldc = d->ldout; g.ldres = d->ldres;
+        g.mode = 1; g.relu_in = d->relu_in; g.relu_out = d->relu_out; g.res_mod = a.res_mod;
+        g.stride = d->stride; g.H = d->H; g.W = d->W; g.Wo = Wo; g.HoWo = Ho * Wo;
+        return gemm_stream_launch(g, pl.sv, pl.sring, s);
+    }
     if (pl.bm == 0) {
         // (a variant with eight output pixels of a row per wave - 3.75 instead of 9 fetches of every input row - measured 28.0 us
         // against 24.9 us for this one-pixel-per-wave form at the 480p mask head: the kernel is bound by its wave reductions and
