@@ -325,6 +325,33 @@ def run_gpu(args, device, rank, world):
                         query_tiles_needing_second_pass=flagged / max(tiles, 1),
                         note='final list length per query after the readout (after the second pass where it ran); '
                              'fraction of 128-query tiles whose lists overflowed in pass 1')
+    # ---- what the convolutions of one frame EXECUTE on the matrix pipe: one hint batch + KB frames of the same schedule run
+    # eagerly with ops.RECORD on (every conv2d call notes its shape, plan, algorithmic FLOPs and the MFMA FLOPs that plan issues:
+    # direct form padded to its tile, F(2x2) 16 / F(4x4) 36 position GEMMs); not part of any reported rate
+    conv_survey = None
+    if rank == 0 and not args.traced_child:
+        start = ((args.warmup + args.steps + inst_frames + 400) // KB + 1) * KB
+        hint(start)                                                  # consumed by the recorded frames; ITS convolutions are not recorded
+        ops.RECORD = []
+        try:
+            for j in range(KB):
+                one_step(start + j)                                  # the first one issues (and records) the next hint batch
+            fetcher.drain(); torch.cuda.synchronize(device)
+        finally:
+            recs, ops.RECORD = ops.RECORD, None
+        forms = {}
+        for kind, key, flop, fn, keep in recs:
+            if kind != 'conv':
+                continue
+            info = keep[5]
+            t = info['plan'][0]
+            form = 'gemv_cout1' if ' ->1/' in key.replace('->', ' ->') else \
+                   ('F(4x4)' if 17 <= t <= 28 else ('F(2x2)' if (7 <= t <= 16 or 29 <= t <= 34) else 'direct'))
+            f = forms.setdefault(form, dict(launches=0, algorithmic_gflop=0.0, executed_mfma_gflop=0.0))
+            f['launches'] += 1; f['algorithmic_gflop'] += flop / 1e9; f['executed_mfma_gflop'] += info['executed_mfma_flops'] / 1e9
+        conv_survey = dict(frames=KB, forms={k: {kk: vv / KB for kk, vv in v.items()} for k, v in forms.items()},
+                           algorithmic_gflop_per_frame=sum(v['algorithmic_gflop'] for v in forms.values()) / KB,
+                           executed_mfma_gflop_per_frame=sum(v['executed_mfma_gflop'] for v in forms.values()) / KB)
     core.cancel_prefetch()
     # ---- the reference surface's rate: step() on one frame at a time, no prefetch_keys (inference/run_on_video.py:98-113)
     plain = None
@@ -345,7 +372,8 @@ def run_gpu(args, device, rank, world):
             args.no_prefetch = saved
     return dict(elapsed=elapsed, preload_s=preload_s, taps=taps, inst_frames=inst_frames, inst_elapsed=inst_elapsed,
                 masks=out_masks, core=core, frames=frames, masks_in=masks, sd=sd, n_query=n_query, base=base,
-                n_elems=n_elems, wl=wl, cfg=cfg, filter_events=filt, candidates=cand, plain=plain, frame_fn=frame)
+                n_elems=n_elems, wl=wl, cfg=cfg, filter_events=filt, candidates=cand, plain=plain, frame_fn=frame,
+                conv_survey=conv_survey)
 
 
 # ---- rocprofv3 kernel trace of the timed region (child process) ------------------------------------------------
@@ -584,7 +612,7 @@ def parse_args(argv=None):
     ap.add_argument('--trace-timeout', type=int, default=420)
     ap.add_argument('--keep-trace', default=None, help='directory to keep the child\'s kernel_trace.csv in')
     ap.add_argument('--traced-child', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--dist-backend', default='nccl', help='control-plane backend for the timing barrier / reductions '
+    ap.add_argument('--dist-backend', default='gloo', help='control-plane backend for the timing barrier / reductions '
                     '(nccl = RCCL; the data path has no collective)')
     return ap.parse_args(argv)
 
@@ -605,15 +633,25 @@ def main():
         local = int(os.environ.get('LOCAL_RANK', '0'))
         if world != args.gpus:
             raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}')
+    dev_index = local
+    if world > 1 and args.dist_backend != 'nccl':
+        # Replica streams exchange nothing on the device: every rank sees ONLY its own GPU (as the video launcher's ranks do), so
+        # that no rank can allocate on or synchronise with a foreign device; the timing barrier and the scalar reductions run
+        # over gloo on the host.  Must happen before the first CUDA call of this process.  (--dist-backend nccl keeps every
+        # device visible for an RCCL control plane instead.)
+        from xmem2_amd.launch import isolated_device_env
+        iso = isolated_device_env(local, os.environ)
+        os.environ.update({k: v for k, v in iso.items() if k != 'LOCAL_RANK'})
+        dev_index = 0
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
-    if torch.cuda.device_count() <= local:
-        raise SystemExit(f'rank {rank}: device {local} requested but only {torch.cuda.device_count()} visible')
-    device = torch.device('cuda', local)
+    if torch.cuda.device_count() <= dev_index:
+        raise SystemExit(f'rank {rank}: device {dev_index} requested but only {torch.cuda.device_count()} visible')
+    device = torch.device('cuda', dev_index)
     torch.cuda.set_device(device)
     if world > 1:                                   # one process per GPU: cores next to the GPU, a bounded intra-op thread pool
         from xmem2_amd.launch import pin_rank
-        pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), max_threads=8, device_index=local)
+        pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), max_threads=8, device_index=dev_index)
     backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -683,7 +721,7 @@ def main():
                                  'yardstick: F_sim / the time of the WHOLE call (all kernels) / the fp32 MFMA peak the contraction ran on before - it '
                                  'exceeds 1 on large memories because the work is not done in fp32 any more',
                          'achieved': filt_tflops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (filt_tflops / PEAK_F16_MFMA_TFLOPS) if filt_tflops else None, 'traffic': None,
+                         'frac': (filt_tflops / PEAK_F16_MFMA_TFLOPS) if filt_tflops else None, 'traffic': None, 'source': 'hip_events',
                          'kernel_avg_us': (1e3 * fe['avg_ms']) if fe else None, 'kernel_median_us': (1e3 * fe['median_ms']) if fe else None,
                          'kernel_launches_timed': fe['launches'] if fe else None,
                          'executed_tflops': (exec_gf / fe['avg_ms']) if fe else None,
@@ -732,11 +770,22 @@ def main():
                 aff_us = fam.get('affinity', {}).get('us_per_frame')
                 if conv_us:
                     ctf = alg['conv'] / (conv_us * 1e-3)
-                    line['conv_roofline'] = {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel / Winograd-domain GEMMs + transform kernels',
-                                             'achieved': ctf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                             'frac': ctf / PEAK_FP32_MFMA_TFLOPS, 'frac_algorithmic': ctf / PEAK_FP32_MFMA_TFLOPS,
-                                             'algorithmic_gflop_per_frame': alg['conv'], 'us_per_frame': conv_us, 'traffic': None,
-                                             'note': 'algorithmic = the DIRECT convolution\'s FLOPs (SURVEY 8d); Winograd F(2x2,3x3) layers execute 2.25x fewer MFMA FLOPs, so the executed-MFMA fraction is lower: see mfma_busy'}
+                    cs = res.get('conv_survey')
+                    etf = (cs['executed_mfma_gflop_per_frame'] / (conv_us * 1e-3)) if cs else None
+                    line['conv_roofline'] = {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel / gemm_stream_kernel (Winograd-domain position GEMMs) + transform kernels',
+                                             'achieved': etf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                             'frac': (etf / PEAK_FP32_MFMA_TFLOPS) if etf else None,
+                                             'executed_mfma_gflop_per_frame': cs['executed_mfma_gflop_per_frame'] if cs else None,
+                                             'executed_by_form': cs['forms'] if cs else None,
+                                             'algorithmic_tflops': ctf, 'algorithmic_speed_vs_fp32_peak': ctf / PEAK_FP32_MFMA_TFLOPS,
+                                             'algorithmic_gflop_per_frame': alg['conv'],
+                                             'algorithmic_gflop_per_frame_surveyed': cs['algorithmic_gflop_per_frame'] if cs else None,
+                                             'us_per_frame': conv_us, 'traffic': None,
+                                             'note': 'achieved / frac = MFMA FLOPs the plans of one frame EXECUTE (direct form padded to its tiles, F(2x2) 16 and F(4x4) 36 '
+                                                     'position GEMMs; surveyed with ops.RECORD over one hint batch + key_batch frames) / the conv family\'s kernel time in the '
+                                                     'marker-cut trace of the timed region (GEMMs AND transform kernels) / the fp32 MFMA peak.  algorithmic_* = the DIRECT '
+                                                     'convolution\'s FLOPs of SURVEY 8(d) over the same time: a speed figure (it exceeds the peak because Winograd executes 1/2.25 '
+                                                     'or 1/4 of those FLOPs), not a roofline fraction'}
                 if aff_us:
                     line['roofline']['timed_region_trace_us_per_frame'] = aff_us
                     line['roofline']['frac_fp32_equivalent_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
@@ -753,6 +802,22 @@ def main():
                                       frac_of_f16_mfma_peak=tf / PEAK_F16_MFMA_TFLOPS,
                                       algorithmic_frac_of_f16_peak=(gf_per_call / (ks[fk]['avg_us'] * 1e-3)) / PEAK_F16_MFMA_TFLOPS)
                         line['roofline']['kernel_avg_us_from_trace'] = ks[fk]['avg_us']
+                        # THE roofline figure: this kernel's launches inside the timed region of the traced child (mean per the
+                        # contract, median beside it: every key_batch-th launch queues behind the other stream's key encoder)
+                        ev = {k: line['roofline'].get(k) for k in ('achieved', 'frac', 'kernel_avg_us', 'kernel_median_us', 'kernel_launches_timed', 'executed_tflops')}
+                        mean_us, med_us = ks[fk]['avg_us'], ks[fk]['median_us']
+                        line['roofline'].update(
+                            achieved=gf_per_call / (mean_us * 1e-3), frac=gf_per_call / (mean_us * 1e-3) / PEAK_F16_MFMA_TFLOPS,
+                            achieved_median=gf_per_call / (med_us * 1e-3) if med_us else None,
+                            frac_median=(gf_per_call / (med_us * 1e-3) / PEAK_F16_MFMA_TFLOPS) if med_us else None,
+                            kernel_avg_us=mean_us, kernel_median_us=med_us, kernel_launches_timed=int(round(ks[fk]['launches_per_frame'] * st)),
+                            executed_tflops=exec_gf / (mean_us * 1e-3), source='timed_region_trace',
+                            from_hip_events=ev,
+                            measured=f'kernel: every launch of {fk} inside the timed region of the rocprofv3 kernel trace of a child copy of this command '
+                                     f'({st} frames, cut by marker kernels): mean (achieved / frac) and median (achieved_median / frac_median).  from_hip_events = the '
+                                     f'same kernel bracketed by HIP events the library records on the launch stream in an extra pass that synchronises after every '
+                                     f'frame (secondary).  Whole call (frac_fp32_equivalent): HIP events around every xmem_affinity_topk_hinted call inside an '
+                                     f'instrumented pass ({res["inst_frames"]} frames; HIP graphs, two streams, batch-{args.key_batch} key hints)')
                     line['roofline']['kernels'] = ks
         pmc = committed_pmc(args.workload, args.precision)
         if pmc is not None:

@@ -238,7 +238,8 @@ int xmem_affinity_debug_offsets(int n_total, int HW, size_t* count_off, size_t* 
 /* Measurement aid: two HIP events (hipEvent_t, created with timing enabled) that the following xmem_affinity_topk_hinted calls
  * record on their stream right before and right after the pass-1 launch of the fp16 filter kernel - the kernel bench.py's
  * `roofline` object is about (the reference times the whole step with perf_counter, inference/run_on_video.py:106-113).
- * NULL, NULL turns it off.  Process-wide, not thread-safe, no effect on results. */
+ * NULL, NULL turns it off.  The pair is held per calling host thread (thread_local): only that thread's later calls record it, so the
+ * library keeps no process-wide mutable state; no effect on results. */
 int xmem_affinity_profile_events(void* before_filter, void* after_filter);
 
 /* Same function with an optional HINT: `idx` are the out_idx [HW][top_k] of an earlier call on the same list of stores (the

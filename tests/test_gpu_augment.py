@@ -85,7 +85,13 @@ def test_batched_preload_equals_frame_by_frame(hip_net):
                        ('selection', a.selection_rows(), b.selection_rows()), ('value', a.value_rows(0), b.value_rows(0))):
         err = float((x - y).abs().max()) / max(float(x.abs().max()), 1e-9)
         assert err < 2e-4, f'{name}: batched preload differs from the sequential one by {err:.2e} of its scale'
-    assert torch.equal(a.rows16().view(torch.int32), a.rows16().view(torch.int32))
+    # the kept fp16 operand rows of the batched preload: one per element, and exactly what the rows kernel derives from the
+    # batched store's own (key, shrinkage) - a stale or misaligned row block after put_many_to_permanent_memory would differ
+    for st in (a, b):
+        r16 = st.rows16()
+        assert r16.shape[0] == st.size
+        fresh = ops.affinity_rows16(st.key_rows().contiguous(), st.shrinkage_rows().contiguous(), torch.empty_like(r16))
+        assert torch.equal(r16.view(torch.int32), fresh.view(torch.int32))
     q = torch.from_numpy(fr[1]).cuda()
     p0, p1 = cores[0].step(q, None, None), cores[1].step(q, None, None)
     assert float((p0 - p1).abs().mean()) < 2e-4 and float((ops.argmax_u8(p0) != ops.argmax_u8(p1)).float().mean()) < 1e-3
@@ -95,7 +101,7 @@ def test_batched_preload_equals_frame_by_frame(hip_net):
 
 
 def test_run_on_video_augmented_preload_device_vs_host(tmp_path, hip_net):
-    """run_on_video(augment_images_with_masks=True): the device path (default) and the host path (augment_on_device=False) give
+    """run_on_video(augment_images_with_masks=True): the device path (opt-in: augment_on_device=True) and the host path (the default) give
     the same masks; the annotated frame enters the memory 12 times either way."""
     from PIL import Image
     from xmem2_amd.run_on_video import run_on_video

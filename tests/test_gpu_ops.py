@@ -86,7 +86,8 @@ def test_conv2d(case):
 
 
 @pytest.mark.parametrize('plan', [(1, 1), (2, 2), (3, 4), (4, 1), (5, 3), (6, 2), (7, 1), (9, 1), (10, 1), (12, 1),
-                                  (13, 1), (14, 1), (15, 1), (17, 1), (19, 1), (22, 1)])
+                                  (13, 1), (14, 1), (15, 1), (17, 1), (19, 1), (22, 1),
+                                  (23, 1), (24, 1), (25, 1), (26, 1), (27, 1), (28, 1), (29, 1), (30, 1), (31, 1), (32, 1)])
 @pytest.mark.parametrize('shape', [(1, 30, 54, 256, 128), (2, 15, 27, 64, 96), (1, 17, 23, 32, 64)])
 def test_conv2d_every_plan(plan, shape):
     """Every tile / split-K / Winograd plan the autotuner may pick computes the same 3x3 convolution."""
@@ -105,6 +106,61 @@ def test_conv2d_every_plan(plan, shape):
     out = ops.conv2d(nhwc(x), cw, res=nhwc(res), relu_in=True, relu_out=True, plan=plan)
     torch.cuda.synchronize()
     close(nchw(out), ref, rtol=2e-4, atol=5e-5, msg=f'conv plan {plan} {shape}')
+
+
+@pytest.mark.parametrize('shape', [(1, 60, 108, 256, 256), (4, 30, 54, 64, 64), (2, 15, 27, 64, 96), (1, 17, 23, 32, 64),
+                                   (3, 9, 13, 96, 192), (1, 120, 216, 64, 64)])
+def test_streaming_gemm_plans_are_bit_identical_to_the_classic_tiles(shape):
+    """The streaming position GEMM (csrc/gemm_stream.hip: LDS-DMA ring, one flat (unit, k-tile) pipeline per workgroup, counted
+    vmcnt waits across unit boundaries) contracts in the classic 64x64 kernel's order: every variant (tile x ring) of plans
+    23..28 must reproduce plan 19 bit for bit, 29..34 plan 9 - ragged tile rows, Cout = 96 / 192 (masked column blocks),
+    Cin = 32 (ONE k-tile per unit: the ring runs NS - 1 units ahead), many units per workgroup."""
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    B, H, W, Cin, Cout = shape
+    gen = g_(Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) * (1.0 / (Cin * 9)) ** 0.5
+    shift = torch.randn(Cout, generator=gen) * 0.1
+    scale = torch.rand(Cout, generator=gen) * 0.5 + 0.75
+    res = nhwc(torch.randn(B, Cout, H, W, generator=gen))
+    cw = ConvWeights(w.permute(0, 2, 3, 1).contiguous().cuda(), scale.cuda(), shift.cuda(), 1, 1)
+    xin = nhwc(x)
+    for base, variants in ((19, range(23, 29)), (9, range(29, 35))):
+        want = ops.conv2d(xin, cw, res=res, relu_in=True, relu_out=True, plan=(base, 1)).clone()
+        for t in variants:
+            got = ops.conv2d(xin, cw, res=res, relu_in=True, relu_out=True, plan=(t, 1))
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), \
+                f'plan {t} differs from plan {base} on {shape}: max |d| {float((got - want).abs().max()):.3e}'
+
+
+@pytest.mark.parametrize('case', [(4, 24, 40, 64, 256, 1, True, True, True), (1, 30, 54, 1024, 256, 1, True, False, True),
+                                  (2, 24, 40, 256, 512, 2, False, False, False), (1, 17, 23, 64, 96, 1, False, True, True),
+                                  (3, 9, 13, 32, 48, 1, True, True, False)])
+def test_streaming_gemm_pointwise_plans(case):
+    """Plans 35..40: the pointwise convolution itself on the streaming kernel with the fused epilogue (scale / shift / residual /
+    relu, relu-on-load, stride 2) - bit-identical to the classic 64x64 tile (plan 3: same k order, same epilogue arithmetic);
+    also through a channel slice of a wider input buffer and with a broadcast residual."""
+    from xmem2_amd import ops
+    from xmem2_amd.ops import ConvWeights
+    B, H, W, Cin, Cout, stride, relu_in, use_res, relu_out = case
+    gen = g_(Cin + 3 * Cout + H)
+    wide = torch.randn(B, H, W, Cin + 32, generator=gen).cuda()
+    w = torch.randn(Cout, 1, 1, Cin, generator=gen) * (1.0 / Cin) ** 0.5
+    cw = ConvWeights(w.cuda(), (torch.rand(Cout, generator=gen) * 0.5 + 0.75).cuda(), (torch.randn(Cout, generator=gen) * 0.1).cuda(), stride, 0)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    for bcast in (False, True):
+        res = torch.randn(1 if bcast else B, Ho, Wo, Cout, generator=gen).cuda() if use_res else None
+        kw = dict(res=res, relu_in=relu_in, relu_out=relu_out, in_ld=Cin + 32, cin=Cin, res_broadcast=bcast)
+        want = ops.conv2d(wide, cw, plan=(3, 1), **kw).clone()
+        for t in range(35, 41):
+            got = ops.conv2d(wide, cw, plan=(t, 1), **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32)), \
+                f'plan {t} differs from plan 3 on {case} (broadcast residual {bcast}): max |d| {float((got - want).abs().max()):.3e}'
+        if not use_res:
+            break
 
 
 def test_winograd_f4_accuracy_at_a_large_layer():

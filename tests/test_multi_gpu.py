@@ -210,8 +210,15 @@ def test_rank_placement_helpers():
             f.write('0-15,128-143\n')
         assert L.gpu_local_cpus('0000:05:00.0', sysfs=d) == list(range(16)) + list(range(128, 144))
         assert L.gpu_local_cpus('0000:06:00.0', sysfs=d) is None and L.gpu_local_cpus(None, sysfs=d) is None
-    assert L.isolated_device_env(3, {}) == dict(HIP_VISIBLE_DEVICES='3', LOCAL_RANK='0', XMEM_DEVICE_ORDINAL='3')
+    assert L.isolated_device_env(3, {}) == dict(HIP_VISIBLE_DEVICES='3', CUDA_VISIBLE_DEVICES='3', LOCAL_RANK='0', XMEM_DEVICE_ORDINAL='3')
     assert L.isolated_device_env(1, {'HIP_VISIBLE_DEVICES': '4,6,7'})['HIP_VISIBLE_DEVICES'] == '6'
+    # a parent limited through the CUDA-style variable only: the ranks stay inside that set, and both variables agree in the child
+    e = L.isolated_device_env(2, {'CUDA_VISIBLE_DEVICES': '4,5,6,7'})
+    assert e['HIP_VISIBLE_DEVICES'] == e['CUDA_VISIBLE_DEVICES'] == e['XMEM_DEVICE_ORDINAL'] == '6'
+    # HIP_VISIBLE_DEVICES wins where both are set (the HIP runtime's own precedence)
+    assert L.isolated_device_env(0, {'HIP_VISIBLE_DEVICES': '2,3', 'CUDA_VISIBLE_DEVICES': '6,7'})['CUDA_VISIBLE_DEVICES'] == '2'
+    with pytest.raises(ValueError):
+        L.isolated_device_env(4, {'CUDA_VISIBLE_DEVICES': '4,5,6,7'})
     # pin_rank in a single-process world changes nothing
     before = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
     info = L.pin_rank(0, 1)

@@ -6,6 +6,8 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fgpu-rdc -c victim_pk.hip -o victim_
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fgpu-rdc -Xclang -target-feature -Xclang -packed-fp32-ops -c victim_nopk.hip -o victim_nopk.o 2>&1 | grep -v "not a recognized feature" || true
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fgpu-rdc -c pk_hazard.hip -o pk_hazard.o
 hipcc --offload-arch=gfx950 -fgpu-rdc victim_pk.o victim_nopk.o pk_hazard.o -o pk_hazard
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fgpu-rdc -Xclang -target-feature -Xclang -packed-fp32-ops -c pk_hazard2.hip -o pk_hazard2.o 2>&1 | grep -v "not a recognized feature" || true
+hipcc --offload-arch=gfx950 -fgpu-rdc victim_pk.o victim_nopk.o pk_hazard2.o -o pk_hazard2
 echo built $(pwd)/pk_hazard
 if [ "$1" = "lib" ]; then
   # the library twice: the shipped build is xmem2_amd/csrc/libxmem_hip.so; here the same sources WITHOUT -packed-fp32-ops

@@ -595,8 +595,9 @@ size_t aff_filter16_mask_bytes(int n_total, int HW) {
 }
 
 // Measurement aid (bench.py): two HIP events the next hinted calls record right before / after their pass-1 filter launch, on the
-// launch stream.  NULL, NULL turns it off.  Process-wide and not thread-safe: a tool's hook, not part of the data path.
-static hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
+// launch stream.  NULL, NULL turns it off.  The pair belongs to the CALLING HOST THREAD (thread_local): calls issued by other threads,
+// on whatever stream or device, never see it - the library keeps no process-wide mutable state.  A tool's hook, not the data path.
+static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
 extern "C" int xmem_affinity_profile_events(void* before_filter, void* after_filter) {
     g_prof_ev[0] = reinterpret_cast<hipEvent_t>(before_filter);
     g_prof_ev[1] = reinterpret_cast<hipEvent_t>(after_filter);

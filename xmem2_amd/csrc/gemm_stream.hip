@@ -22,6 +22,16 @@
 // MFMA lane maps and the k permutation are those of conv_mfma.hip: a lane reads 4 consecutive k (one 16-byte chunk, chunk index
 // 2 kk + (lane >> 5) of k-group kk) and MFMA step j contracts k = {j, 4 + j} of the group for A and B alike.
 #include "gemm_stream.hpp"
+#include <stdlib.h>
+
+// Tools knobs (XMEM_STREAM_DBG, only in a -DXMEM_TOOLS build: XMEM_HIPCC_FLAGS=-DXMEM_TOOLS python -m xmem2_amd.build --force):
+// 1 = every unit loads unit 0's operands, 2 = no stores, 4 = no barrier, 8 = no LDS-DMA in the loop, 16 = MFMAs on constants,
+// 32 = contiguous unit runs per workgroup.  Results are wrong with any of 1..16; they exist to attribute time.
+#ifdef XMEM_TOOLS
+#define DBG(bit) (p.dbg & (bit))
+#else
+#define DBG(bit) 0
+#endif
 
 namespace {
 
@@ -29,6 +39,11 @@ namespace {
 // M0 is written in the statement that reads it (the compiler does not preserve it across statements).
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_loads_only() {    // tools (XMEM_STREAM_DBG & 4): the same wait without the barrier - results are then wrong
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 
 template <int N>
@@ -58,10 +73,16 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int u0 = bid * p.units_per_wg;
-    const int u1 = min(p.units, u0 + p.units_per_wg);
+    // Units are dealt round-robin over the (XCD-ordered) workgroups: at any time the workgroups of one XCD walk a narrow band of
+    // consecutive units - one tile position, a few dozen row tiles, all column tiles - so that both operands of the band stay in
+    // that XCD's 4 MiB L2 (contiguous runs per workgroup, as first written, spread the resident workgroups over all 36
+    // positions: 9.4 MB of weights in flight, L2 hit rate 0.43 instead of 0.65, 4x the algorithmic fetch bytes).
+    const int ustep = DBG(32) ? 1 : (int)gridDim.x;
+    const int u0 = DBG(32) ? bid * p.units_per_wg : bid;
+    const int u1 = DBG(32) ? min(p.units, u0 + p.units_per_wg) : p.units;
     if (u0 >= u1) return;
-    const int S = (u1 - u0) * p.nk;                    // pipeline steps of this workgroup
+    const int nunits = (u1 - u0 + ustep - 1) / ustep;
+    const int S = nunits * p.nk;                       // pipeline steps of this workgroup
     const unsigned lds_base = (unsigned)(size_t)smem;  // LDS byte address of the ring (low half of the flat address)
 
     // ---- load side -------------------------------------------------------------------------------------------------
@@ -72,7 +93,8 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
     const char* ld_abase = nullptr;
     const char* ld_bbase = nullptr;
     auto ld_unit_setup = [&]() {                       // operand row offsets of unit ld_u (rows past M / N are clamped: never stored)
-        const int tn = ld_u % p.tiles_n, t2 = ld_u / p.tiles_n;
+        const int lu = DBG(1) ? 0 : ld_u;
+        const int tn = lu % p.tiles_n, t2 = lu / p.tiles_n;
         const int tm = t2 % p.tiles_m, g = t2 / p.tiles_m;
         const int m0 = tm * BM, n0 = tn * BN;
 #pragma unroll
@@ -106,7 +128,8 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
         for (int i = 0; i < LB; ++i) glds16(bb, b_voff[i], dst + BM * 128 + i * 4096);
         if (++ld_kt == p.nk) {
             ld_kt = 0;
-            if (++ld_u < u1) ld_unit_setup();
+            ld_u += ustep;
+            if (ld_u < u1) ld_unit_setup();
         }
     };
 
@@ -133,7 +156,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
     constexpr int WAIT_STEADY = L * (NS - 2);
     constexpr int WAIT_CREDIT = (WAIT_STEADY + ST > 63) ? 63 : WAIT_STEADY + ST;
     int s = 0, stage = 0, credit = 0;
-    for (int cu = u0; cu < u1; ++cu) {
+    for (int cu = u0; cu < u1; cu += ustep) {
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -145,19 +168,38 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
         for (int kt = 0; kt < p.nk; ++kt, ++s) {
             // loads of steps s+1 .. s+NS-2 may stay in flight (L each); the tail of the run has fewer steps behind it
             const int behind = S - 1 - s;
-            if (behind >= NS - 2) {
+            if (DBG(4)) wait_loads_only<WAIT_STEADY>();
+            else if (behind >= NS - 2) {
                 if (ST > 0 && credit > 0) wait_loads_then_barrier<WAIT_CREDIT>();
                 else wait_loads_then_barrier<WAIT_STEADY>();
             } else if (NS > 3 && behind == 1) wait_loads_then_barrier<L>();
             else wait_loads_then_barrier<0>();
             if (credit > 0) --credit;
-            if (s + NS - 1 < S) {
+            if (s + NS - 1 < S && !DBG(8)) {
                 int st = stage + NS - 1; if (st >= NS) st -= NS;
                 issue(st);                              // refills the stage every wave finished reading before this barrier
             }
 
-            const unsigned char* sb = smem + stage * STAGE;
+            const unsigned char* sb = smem + (DBG(16) ? 0 : stage * STAGE);
             f32x4 af[2][TM], bf[2][TN];
+            if (DBG(16)) {                         // tools: MFMAs on register constants, no fragment reads
+                const f32x4 c = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { af[0][i] = c; af[1][i] = c; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { bf[0][j] = c; bf[1][j] = c; }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][i][t], bf[0][j][t], acc[i][j], 0, 0, 0);
+                if (++stage == NS) stage = 0;
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(sb + rd_a[0] + i * 4096);
 #pragma unroll
@@ -196,6 +238,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
         const int m0 = tm * BM, n0 = tn * BN;
         float* const cg = p.C + (size_t)g * p.c_gstride;
         bool all_full = true;
+        if (DBG(2)) { credit = 0; continue; }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nb = n0 + wn * 32 * TN + j * 32;             // wave-uniform first column of the block
@@ -268,6 +311,8 @@ int gemm_stream_launch(GemmStreamArgs& a, int variant, int ring, hipStream_t s) 
     if (a.K % 32 != 0 || a.K <= 0 || a.M <= 0 || a.N <= 0 || a.G <= 0) return XMEM_ERR_UNSUPPORTED;
     if (variant < 0 || variant > 2 || (ring != 3 && ring != 4)) return XMEM_ERR_BAD_ARG;
     const int bm = variant == 0 ? 64 : 128, bn = variant == 2 ? 128 : 64;
+    static const int dbg = getenv("XMEM_STREAM_DBG") ? atoi(getenv("XMEM_STREAM_DBG")) : 0;
+    a.dbg = dbg;
     a.nk = a.K / 32;
     a.tiles_m = cdiv(a.M, bm); a.tiles_n = cdiv(a.N, bn);
     const long units = (long)a.G * a.tiles_m * a.tiles_n;
@@ -279,7 +324,7 @@ int gemm_stream_launch(GemmStreamArgs& a, int variant, int ring, hipStream_t s) 
     int per_cu = (int)((160 * 1024) / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
     const int slots = 256 * per_cu;
     a.units_per_wg = cdiv(a.units, slots);
-    const int nwg = cdiv(a.units, a.units_per_wg);
+    const int nwg = cdiv(a.units, a.units_per_wg);     // every workgroup gets units_per_wg (the last ones one fewer) units, strided by nwg
     if (variant == 0) return ring == 3 ? launch_variant<1, 1, 3>(a, nwg, s) : launch_variant<1, 1, 4>(a, nwg, s);
     if (variant == 1) return ring == 3 ? launch_variant<2, 1, 3>(a, nwg, s) : launch_variant<2, 1, 4>(a, nwg, s);
     return ring == 3 ? launch_variant<2, 2, 3>(a, nwg, s) : launch_variant<2, 2, 4>(a, nwg, s);

@@ -19,6 +19,7 @@ struct GemmStreamArgs {
     int relu_in, relu_out, res_mod;
     // strided pointwise convolution (mode 1): A row of output pixel m is input pixel ((b*H + oh*stride)*W + ow*stride)
     int stride, H, W, Wo, HoWo;
+    int dbg;                   // tools only (XMEM_STREAM_DBG): 1 = every unit loads unit 0's operands, 2 = no stores; results are then wrong
 };
 
 // variant: 0 = 64x64 tile, 1 = 128x64, 2 = 128x128 (rows x columns of C per workgroup); ring = LDS stages (3 or 4)

@@ -58,13 +58,20 @@ def visible_gpus():
 
 
 def isolated_device_env(r, parent_env):
-    """Environment that shows rank r exactly ONE GPU (the r-th of what the parent sees): HIP_VISIBLE_DEVICES=<id>, LOCAL_RANK=0.
-    A rank then cannot allocate on, or synchronise with, another rank's device by accident (torch's default device 0 IS its
-    own GPU).  XMEM_DEVICE_ORDINAL keeps the node-wide ordinal for CPU pinning and logs."""
+    """Environment that shows rank r exactly ONE GPU (the r-th of what the parent sees), LOCAL_RANK=0.  The parent's set is read
+    from HIP_VISIBLE_DEVICES, else from CUDA_VISIBLE_DEVICES (a node shared through the CUDA-style variable, which the HIP
+    runtime honours when its own is absent); BOTH variables are set to the rank's id in the child so that they cannot disagree
+    (a child given only HIP_VISIBLE_DEVICES=r under a parent limited by CUDA_VISIBLE_DEVICES=4,5,6,7 would land on physical GPU r,
+    outside the allotted set).  A rank then cannot allocate on, or synchronise with, another rank's device by accident (torch's
+    default device 0 IS its own GPU).  XMEM_DEVICE_ORDINAL keeps the node-wide ordinal for CPU pinning and logs."""
     vis = parent_env.get('HIP_VISIBLE_DEVICES')
+    if vis is None or vis.strip() == '':
+        vis = parent_env.get('CUDA_VISIBLE_DEVICES')
     ids = [v.strip() for v in vis.split(',') if v.strip() != ''] if vis else None
-    dev = ids[r] if ids and r < len(ids) else str(r)
-    return dict(HIP_VISIBLE_DEVICES=dev, LOCAL_RANK='0', XMEM_DEVICE_ORDINAL=dev)
+    if ids is not None and r >= len(ids):
+        raise ValueError(f'rank {r} has no device: the visible set is {ids}')
+    dev = ids[r] if ids else str(r)
+    return dict(HIP_VISIBLE_DEVICES=dev, CUDA_VISIBLE_DEVICES=dev, LOCAL_RANK='0', XMEM_DEVICE_ORDINAL=dev)
 
 
 def spawn_ranks(argv, world, extra_env=None, check_devices=True, timeout=None, isolate_devices=False, nonce=None):

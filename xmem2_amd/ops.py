@@ -108,8 +108,11 @@ def time_recorded(records, reps=10):
 def workspace(nbytes, device, tag='default'):
     """Grow-only scratch buffer per (device, tag + scope suffix); kernels on one stream run in order so reuse is safe.
     The scope suffix (`ws_scope`, entered by XMem around its side-stream key-encoder stages, unique per network instance and
-    graph slot) keeps concurrently running streams on separate scratch; it is thread-local, so two host threads driving
-    different networks do not see each other's scope."""
+    graph slot) keeps concurrently running streams on separate scratch.
+    CONTRACT: one host thread drives this module per process (as the reference's InferenceCore is single-threaded).
+    The scope suffix is thread-local, but the precision mode (`ops.precision`) is a process-wide switch and un-scoped scratch
+    ('conv', 'affinity', 'augment', ... without a scope) is shared per device by every caller on every stream: two host threads
+    calling into ops concurrently would clobber each other's mode and scratch.  Run one process per stream of videos (launch.py)."""
     key = (str(device), tag + getattr(_tls, 'suffix', ''))      # kernels on a side stream get their own scratch
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -349,6 +352,85 @@ def _tune_conv(lib, d, x_device, cw=None):
     return best
 
 
+# Streaming-GEMM variants of a tabled Winograd plan (csrc/gemm_stream.hip): plan 19 (F(4x4), 64x64 tile) -> 23 (64x64, ring 3),
+# 26 (64x64, ring 4), 24 (128x64, ring 3); plan 9 (F(2x2)) -> 29, 32.  XMEM_TUNE_STREAM=1 (tools/tune_convs.py) times the tabled
+# plan against them once per shape and keeps a variant only when it is at least 3 % faster (same arithmetic, same summation
+# order: results are bit-identical either way).
+TUNE_STREAM = os.environ.get('XMEM_TUNE_STREAM', '0') == '1'
+_STREAM_VARIANTS = {19: (23, 26, 24), 9: (29, 32)}
+_stream_checked = set()
+
+
+def _time_plan(lib, d, dev, plan, reps=12):
+    d.plan_tile, d.plan_splitk = plan
+    need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
+    ws = workspace(need, dev, 'conv') if need else None
+    st = stream_ptr()
+    for _ in range(3):
+        if lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, st) != 0:
+            return None
+    best = None
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, st)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) / reps
+        best = t if best is None or t < best else best
+    return best
+
+
+def _tune_stream(lib, d, dev, plan):
+    base = _time_plan(lib, d, dev, plan)
+    best, best_t = plan, base
+    if base is not None:
+        for t in _STREAM_VARIANTS[plan[0]]:
+            tt = _time_plan(lib, d, dev, (t, 1))
+            if tt is not None and tt < 0.97 * base and tt < best_t:
+                best, best_t = (t, 1), tt
+    return best
+
+
+_TILES = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 128), 5: (128, 64), 6: (64, 64)}
+_STREAM_TILES = ((64, 64), (128, 64), (128, 128))
+
+
+def conv_executed_mfma_flops(B, Ho, Wo, cin, cout, kh, kw, stride, pad, plan_tile, winograd_ok):
+    """MFMA FLOPs the library really issues for one conv2d call under `plan_tile` (what an EXECUTED roofline fraction must count,
+    bench.py conv_roofline): the direct form contracts 2 * M * Cout * KH * KW * Cin with M / Cout padded to the tile and K to the
+    32-deep k-tile; F(2x2) runs 16 position GEMMs over ceil(Ho/2) * ceil(Wo/2) tiles per image (1/2.25 of the direct FLOPs before
+    padding), F(4x4) 36 over ceil(Ho/4) * ceil(Wo/4) (1/4).  Cout = 1 is a VALU GEMV: no MFMA work.  Mirrors make_plan() of
+    csrc/conv_mfma.hip; the built-in heuristic (plan 0) is counted with the 64x64 tile."""
+    if cout == 1:
+        return 0.0
+    t = int(plan_tile)
+    up = lambda a, b: -(-a // b) * b
+    form, tile = 'direct', (64, 64)
+    if 23 <= t <= 40:
+        grp, v = (t - 23) // 6, (t - 23) % 6
+        tile = _STREAM_TILES[v % 3]
+        form = ('f4', 'f2', 'direct')[grp]
+    elif 17 <= t <= 22:
+        form, tile = 'f4', _TILES[t - 16]
+    elif t == 16:
+        form, tile = 'f2', (64, 64)
+    elif 13 <= t <= 15:
+        form, tile = 'f2', {13: (128, 64), 14: (64, 64), 15: (64, 128)}[t]
+    elif 7 <= t <= 12:
+        form, tile = 'f2', _TILES[t - 6]
+    elif 1 <= t <= 6:
+        tile = _TILES[t]
+    if form != 'direct' and not winograd_ok:
+        form = 'direct'
+    if form == 'direct':
+        return 2.0 * up(B * Ho * Wo, tile[0]) * up(cout, tile[1]) * up(kh * kw * cin, 32)
+    r, npos = (4, 36) if form == 'f4' else (2, 16)
+    tiles = B * (-(-Ho // r)) * (-(-Wo // r))
+    return npos * 2.0 * up(tiles, tile[0]) * up(cout, tile[1]) * up(cin, 32)
+
+
 def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None, plan=None,
            res_broadcast=False):
     """x [B,H,W,C] NHWC (or any buffer whose pixel stride is `in_ld`) -> out [B,Ho,Wo,Cout]."""
@@ -428,9 +510,9 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             cw.wu4 = winograd4_weights(cw.w)
         d.w_winograd4 = cw.wu4.data_ptr()
         plan = (plan[0] + 10, plan[1])
-    elif 17 <= plan[0] <= 22 and (not WINO4 or CONV_FORM == 'f2') and not explicit:
-        plan = (plan[0] - 10, plan[1])               # XMEM_WINO4=0: the same GEMM tile under F(2x2)
-    elif 17 <= plan[0] <= 22:
+    elif (17 <= plan[0] <= 22 or 23 <= plan[0] <= 28) and (not WINO4 or CONV_FORM == 'f2') and not explicit:
+        plan = (plan[0] - 10 if plan[0] <= 22 else plan[0] + 6, plan[1])     # XMEM_WINO4=0: the same GEMM tile under F(2x2)
+    elif 17 <= plan[0] <= 28:                        # F(4x4): classic tiles 17..22, streaming GEMM 23..28
         if cw.wu4 is None and cw.wu is not None:
             cw.wu4 = winograd4_weights(cw.w)
         d.w_winograd4 = cw.wu4.data_ptr() if cw.wu4 is not None else None
@@ -439,6 +521,11 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
             raise RuntimeError('conv2d: split operands must be built before graph capture (run the stage eagerly once)')
         cw.ensure_split()
         d.w_winograd4_split = cw.wu4_sp.data_ptr()
+    if TUNE_STREAM and not explicit and plan[0] in _STREAM_VARIANTS and d.arith == 0 and key not in _stream_checked \
+            and not torch.cuda.is_current_stream_capturing():
+        _stream_checked.add(key)
+        plan = _tune_stream(lib, d, x.device, tuple(plan))
+        _tuned_now[key] = plan
     d.plan_tile, d.plan_splitk = plan
     if _SPLIT_CHECK and d.arith == 1 and not torch.cuda.is_current_stream_capturing():
         # tools: the same call in fp32 first, then compare (XMEM_SPLIT_CHECK=1; synchronises)
@@ -469,7 +556,10 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         RECORD.append(('conv', key, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true,
                        lambda: lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()),
                        (x, out, res, cw, ws, dict(relu_in=bool(relu_in), relu_out=bool(relu_out), in_ld=ldin, cin=cin, out_ld=out_ld,
-                                                  res_broadcast=bool(res_broadcast)))))
+                                                  res_broadcast=bool(res_broadcast), plan=tuple(plan),
+                                                  executed_mfma_flops=conv_executed_mfma_flops(
+                                                      B, Ho, Wo, cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, plan[0],
+                                                      bool(d.w_winograd) and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0))))))
     return out
 
 

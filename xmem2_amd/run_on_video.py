@@ -302,7 +302,10 @@ def _inference_on_video(frames_with_masks, imgs_in_path, masks_in_path, masks_ou
             msk = vid_reader.resize_mask(msk)
         processor.set_all_labels(list(mapper.remappings.values()))
         a = perf_counter()
-        on_device = augment_images_with_masks and not sample.need_resize and config.get('augment_on_device', True)
+        # Opt-in (config['augment_on_device'] = True; default False): the device path is pinned to this repo's host restatement only
+        # to float ties (blur within 1 LSB, < 2e-4 of the pixels of the nearest-sampling transforms, batched conv plans ~2e-4), and the
+        # default output is the fp32 parity contract - a caller chooses the 20x faster preload knowingly.
+        on_device = augment_images_with_masks and not sample.need_resize and config.get('augment_on_device', False)
         if on_device:
             # the annotated frame and its 11 'best_all' augmentations: made on the device in one launch, preloaded through ONE
             # batched key + value pass (the reference runs 12 sequential passes over host-side PIL transforms, :231-242).
