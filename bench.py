@@ -377,7 +377,7 @@ def run_gpu(args, device, rank, world):
 
 
 # ---- rocprofv3 kernel trace of the timed region (child process) ------------------------------------------------
-FAMILIES = (('conv', ('conv_', 'wino_', 'wino4_')),
+FAMILIES = (('conv', ('conv_', 'wino_', 'wino4_', 'gemm_stream_')),
             ('affinity', ('affinity_',)),
             ('readout', ('readout_sparse_kernel',)),
             ('usage', ('usage_',)),
@@ -388,6 +388,7 @@ FAMILIES = (('conv', ('conv_', 'wino_', 'wino4_')),
 
 def family_of(name):
     n = name[5:] if name.startswith('void ') else name
+    n = n.replace('(anonymous namespace)::', '')
     if n.startswith('_Z'):                               # a name the tracer could not demangle (_Float16 arguments)
         n = n[2:].lstrip('0123456789')
     for fam, prefixes in FAMILIES:
@@ -404,7 +405,8 @@ def parse_kernel_trace(path):
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].strip()))
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']),
+                         r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].strip()))
     rows.sort()
     marks = [r for r in rows if r[2].startswith('xmem_trace_marker_kernel')]
     if len(marks) < 2:

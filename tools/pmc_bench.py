@@ -36,7 +36,7 @@ def run_pass(counters, args):
     rows = []
     with open(max(files, key=os.path.getsize)) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r.get('Dispatch_Id', 0)), r['Kernel_Name'].split('(')[0].strip(), r['Counter_Name'], float(r['Counter_Value'])))
+            rows.append((int(r.get('Dispatch_Id', 0)), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].strip(), r['Counter_Name'], float(r['Counter_Value'])))
     shutil.rmtree(tmp, ignore_errors=True)
     rows.sort()
     marks = [d for d, n, c, v in rows if n.startswith('xmem_trace_marker_kernel')]

@@ -24,7 +24,8 @@ class ConvDesc(C.Structure):
                 ('out', C.c_void_p), ('ldout', C.c_int),
                 ('relu_in', C.c_int), ('relu_out', C.c_int), ('plan_tile', C.c_int), ('plan_splitk', C.c_int), ('w_winograd', C.c_void_p),
                 ('res_broadcast', C.c_int), ('w_winograd_f16', C.c_void_p), ('w_winograd4', C.c_void_p),
-                ('arith', C.c_int), ('w_split', C.c_void_p), ('w_winograd_split', C.c_void_p), ('w_winograd4_split', C.c_void_p)]
+                ('arith', C.c_int), ('w_split', C.c_void_p), ('w_winograd_split', C.c_void_p), ('w_winograd4_split', C.c_void_p),
+                ('in_half', C.c_int), ('out_half', C.c_int), ('w_half', C.c_void_p)]
 
 
 class AugDesc(C.Structure):

@@ -63,7 +63,13 @@ __device__ __forceinline__ f32x4 split_pack(const f32x4 v) {
 // plain matrix rows, so each thread keeps loop-invariant 32-bit byte offsets and the K loop only advances a uniform base -
 // no per-tile index arithmetic, bounds tests or exec-masked branches around the loads (rows past M / Cout are clamped:
 // their products are never stored).  The address VALU work of the general loader was comparable to the MFMA issue time.
-template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false, bool SPLIT = false>
+// HALF (the fp16 loop, config['precision'] = 'fp16': the counterpart of the reference's autocast frame loop,
+// inference/run_on_video.py:76): activations and weights are IEEE halfs in memory, contracted on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation; the epilogue (scale / shift / residual / relu) runs in fp32 and the result is stored as fp32 (HALF = 1: key
+// projection, split-K partials) or rounded once to fp16 (HALF = 2: every activation).  Eight halfs occupy the 16 bytes of four
+// floats, so with Cin, ldin and K passed in 4-byte units (Cin / 2, ...) every loader of this file is unchanged; a 16-byte
+// fragment is ONE fp16 MFMA (k = 16: 8 halfs per lane half) instead of four fp32 ones.
+template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false, bool SPLIT = false, int HALF = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WN = BN / (32 * TN);
     constexpr int WM = BM / (32 * TM);
@@ -181,8 +187,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         if (p.relu_in) {                       // relu-on-load, applied when the data is consumed (never right after the
 #pragma unroll                                 // global load: that would stall the wave before its MFMAs)
             for (int i = 0; i < RA; ++i) {
-                ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
-                ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+                if (HALF) {
+                    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(h16x8, ra[i]), z));
+                } else {
+                    ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
+                    ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
+                }
             }
         }
         if (SPLIT && !p.a_presplit) {          // fp32 activations become [hi4|lo4] groups on their way into LDS
@@ -233,7 +244,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDK + (kk + 1) * 8);
             }
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch above this k-group's MFMAs
-            if (SPLIT) {
+            if (HALF) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, af[cur][i]), __builtin_bit_cast(h16x8, bf[cur][j]),
+                                                                           acc[i][j], 0, 0, 0);
+            } else if (SPLIT) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const h16x8 b = __builtin_bit_cast(h16x8, bf[cur][j]);
@@ -265,6 +283,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     const int mode = p.raw ? 0 : (p.splitk > 1 ? 1 : (p.res ? 3 : 2));
     float* const obase = (mode == 1) ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : gout;
     const long ldo = (mode == 1) ? (long)p.Cout : (long)p.ldout;
+    const bool half_io = (HALF == 2) && mode >= 2;                        // activations (output and residual) are halfs; ldout / ldres count halfs
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * 32 * TN + j * 32 + l31;
@@ -275,6 +294,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * 32 * TM + i * 32 + 4 * lh;          // this lane's rows: mb + (r & 3) + 8 * (r >> 2)
             float* const orow = obase + (size_t)mb * ldo + n;
+            _Float16* const orow_h = reinterpret_cast<_Float16*>(obase) + (size_t)mb * ldo + n;
             float rv[16];
             if (mode == 3) {
                 int mr = p.res_mod ? mb % p.res_mod : mb;                 // broadcast residual: row index modulo one image
@@ -284,7 +304,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     const int o = (r & 3) + 8 * (r >> 2);
                     int t = mr + o;
                     if (p.res_mod) { if (wrap_ok) { if (t >= p.res_mod) t -= p.res_mod; } else t = (mb + o) % p.res_mod; }
-                    rv[r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
+                    if (half_io) rv[r] = (mb + o < p.M) ? (float)reinterpret_cast<const _Float16*>(p.res)[(size_t)t * p.ldres + n] : 0.f;
+                    else rv[r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
                 }
             }
 #pragma unroll
@@ -297,12 +318,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
                     if (mode == 3) v += rv[r];
                     if (p.relu_out) v = fmaxf(v, 0.f);
                 }
-                orow[(long)o * ldo] = v;
+                if (half_io) orow_h[(long)o * ldo] = (_Float16)v;
+                else orow[(long)o * ldo] = v;
             }
         }
     }
 }
 
+template <bool HALF_IO>
 __global__ void conv_splitk_reduce_kernel(ConvArgs p) {
     const size_t total = (size_t)p.M * p.Cout;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -310,14 +333,17 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs p) {
         float v = 0.f;
         for (int z = 0; z < p.splitk; ++z) v += p.partial[(size_t)z * total + e];
         v = v * p.scale[n] + p.shift[n];
-        if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres + n];
+        const size_t ri = (size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres + n;
+        if (p.res) v += HALF_IO ? (float)reinterpret_cast<const _Float16*>(p.res)[ri] : p.res[ri];
         if (p.relu_out) v = fmaxf(v, 0.f);
-        p.out[(size_t)m * p.ldout + n] = v;
+        if (HALF_IO) reinterpret_cast<_Float16*>(p.out)[(size_t)m * p.ldout + n] = (_Float16)v;
+        else p.out[(size_t)m * p.ldout + n] = v;
     }
 }
 
 // Cout == 1 (the decoder's mask head, model/modules.py:242): a GEMV per pixel - one wave per output pixel,
 // lanes over input channels (float4), wave reduction.  HBM/L2-bound instead of wasting a 64-wide MFMA tile.
+template <bool HALF_IN>
 __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -331,13 +357,23 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
         for (int kw = 0; kw < p.KW; ++kw) {
             const int iw = ow * p.stride - p.pad + kw;
             if ((unsigned)iw >= (unsigned)p.W) continue;
-            const float* x = p.in + ((size_t)(b * p.H + ih) * p.W + iw) * p.ldin;
+            const float* x = p.in + ((size_t)(b * p.H + ih) * p.W + iw) * p.ldin;      // HALF_IN: Cin / ldin count 4-byte units (two halfs)
             const float* w = p.w + (size_t)(kh * p.KW + kw) * p.Cin;
             for (int c = lane * 4; c < p.Cin; c += 256) {
                 f32x4 xv = *reinterpret_cast<const f32x4*>(x + c);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
-                if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
-                acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+                if (HALF_IN) {
+                    const h16x8 xh = __builtin_bit_cast(h16x8, xv), wh = __builtin_bit_cast(h16x8, wv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float xe = (float)xh[e];
+                        if (p.relu_in) xe = fmaxf(xe, 0.f);
+                        acc = fmaf(xe, (float)wh[e], acc);
+                    }
+                } else {
+                    if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+                    acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+                }
             }
         }
     }
@@ -890,7 +926,7 @@ __global__ __launch_bounds__(256) void wino_gemm_f16_kernel(WinoF16Args p) {
 namespace {
 
 struct Plan { int bm, bn, bk, splitk, kt_per_split, nk; bool generic; bool wino; int fused; bool f16; bool wino4; bool split;
-              int stream, sv, sring; };      // stream: 1 = GEMM on the streaming kernel (csrc/gemm_stream.hip), tile variant sv, ring sring
+              int stream, sv, sring; int half; };      // stream: 1 = GEMM on the streaming kernel (csrc/gemm_stream.hip), tile variant sv, ring sring
 
 inline bool wino_ok(const xmem_conv_desc* d) {
     return d->w_winograd && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 32 == 0 && d->Cout % 4 == 0 &&
@@ -924,7 +960,7 @@ Plan make_plan(const xmem_conv_desc* d) {
     pl.fused = 0;
     pl.f16 = false;
     pl.wino4 = false;
-    pl.stream = 0; pl.sv = 0; pl.sring = 3;
+    pl.stream = 0; pl.sv = 0; pl.sring = 3; pl.half = 0;
     // split-operand arithmetic ('fp32x', opt-in): every GEMM-shaped path; the Cout = 1 GEMV stays fp32 (it is HBM-bound)
     pl.split = d->arith == 1 && d->w_split != nullptr;
     if (d->Cout == 1) { pl.split = false; pl.bm = 0; pl.bn = 0; pl.nk = cdiv(K, 32); pl.splitk = 1; pl.kt_per_split = pl.nk; return pl; }   // GEMV path
@@ -1016,10 +1052,14 @@ static bool conv_is_one(const ConvArgs& a) {
 }
 
 template <int BM, int BN, int TM, int TN, int BK, bool G>
-int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = false) {
+int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = false, int half = 0) {
     const size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false, false>;
-    if (split) {
+    if (half && BK == 32) {                        // fp16 loop: half operands (HALF 1: fp32 output, 2: half output + residual)
+        const bool one = !G && conv_is_one(a);
+        if (half == 2) kern = one ? conv_mfma_kernel<BM, BN, TM, TN, 32, false, true, false, 2> : conv_mfma_kernel<BM, BN, TM, TN, 32, G, false, false, 2>;
+        else kern = one ? conv_mfma_kernel<BM, BN, TM, TN, 32, false, true, false, 1> : conv_mfma_kernel<BM, BN, TM, TN, 32, G, false, false, 1>;
+    } else if (split) {
         kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false, true>;
         if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true, true>;
     } else if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true, false>;
@@ -1034,15 +1074,30 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = fa
 
 template <int BK, bool G>
 int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s, int groups = 1) {
-    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s, groups, pl.split);
-    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s, groups, pl.split);
-    return launch_cfg<64, 64, 1, 1, BK, G>(a, s, groups, pl.split);
+    if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s, groups, pl.split, pl.half);
+    if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s, groups, pl.split, pl.half);
+    return launch_cfg<64, 64, 1, 1, BK, G>(a, s, groups, pl.split, pl.half);
 }
 
 }  // namespace
 
+// fp16 loop: the descriptor as the fp32 machinery sees it - channels in 4-byte units (two halfs), direct plans only
+static bool half_view(const xmem_conv_desc* d, xmem_conv_desc& v) {
+    if (!d->w_half || d->Cin % 8 != 0 || d->ldin % 8 != 0 || (((uintptr_t)d->in) & 15) != 0 || (((uintptr_t)d->w_half) & 15) != 0) return false;
+    v = *d;
+    v.Cin = d->Cin / 2; v.ldin = d->ldin / 2;
+    v.w_winograd = nullptr; v.w_winograd4 = nullptr; v.w_winograd_f16 = nullptr; v.arith = 0; v.w_split = nullptr;
+    if (v.plan_tile > 3) v.plan_tile = (v.plan_tile <= 6) ? v.plan_tile - 3 : 0;      // BK = 32 (64 halfs) tiles only
+    return true;
+}
+
 extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
     if (validate(d) != XMEM_OK) return 0;
+    xmem_conv_desc hv;
+    if (d->in_half) {
+        if (!half_view(d, hv)) return 0;
+        d = &hv;
+    }
     Plan pl = make_plan(d);
     int Ho, Wo; out_dims(d, Ho, Wo);
     if (pl.wino && pl.wino4) return (size_t)36 * d->B * cdiv(Ho, 4) * cdiv(Wo, 4) * (d->Cin + d->Cout) * sizeof(float);
@@ -1057,10 +1112,18 @@ extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
 extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = validate(d);
     if (rc != XMEM_OK) return rc;
+    xmem_conv_desc hv;
+    const int half = d->in_half ? (d->out_half ? 2 : 1) : 0;
+    if (half) {
+        if (d->out_half && d->Cout == 1) return XMEM_ERR_UNSUPPORTED;      // the mask head writes fp32 logits
+        if (!half_view(d, hv)) return XMEM_ERR_UNSUPPORTED;
+        d = &hv;
+    } else if (d->out_half) return XMEM_ERR_UNSUPPORTED;                    // half output needs half input (the stems stay fp32)
     Plan pl = make_plan(d);
+    pl.half = half;
     int Ho, Wo; out_dims(d, Ho, Wo);
     ConvArgs a;
-    a.in = d->in; a.w = pl.split ? reinterpret_cast<const float*>(d->w_split) : d->w;
+    a.in = d->in; a.w = half ? reinterpret_cast<const float*>(d->w_half) : (pl.split ? reinterpret_cast<const float*>(d->w_split) : d->w);
     a.scale = d->scale; a.shift = d->shift; a.res = d->res; a.out = d->out;
     a.a_presplit = 0;
     a.partial = reinterpret_cast<float*>(workspace);
@@ -1202,7 +1265,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         // (a variant with eight output pixels of a row per wave - 3.75 instead of 9 fetches of every input row - measured 28.0 us
         // against 24.9 us for this one-pixel-per-wave form at the 480p mask head: the kernel is bound by its wave reductions and
         // load latency, not by the L2 reads; removed)
-        hipLaunchKernelGGL(conv_cout1_kernel, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
+        if (half) hipLaunchKernelGGL(conv_cout1_kernel<true>, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_cout1_kernel<false>, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
         return xmem_check_launch();
     }
     if (pl.bk == 64) rc = pl.generic ? launch_bk<64, true>(pl, a, s) : launch_bk<64, false>(pl, a, s);
@@ -1211,7 +1275,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     if (pl.splitk > 1) {
         const size_t total = (size_t)a.M * a.Cout;
         int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+        if (half == 2) hipLaunchKernelGGL(conv_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
         rc = xmem_check_launch();
     }
     return rc;

@@ -12,10 +12,35 @@ inline int grid_for(size_t n, int block = 256, int cap = 8192) {
 }
 }  // namespace
 
+// Storage types of the fp16 loop (config['precision'] = 'fp16'): activations may live in HBM as IEEE halfs; every kernel below
+// computes in fp32 and converts at its loads / stores (one rounding to nearest even per stored value).  The `_t` entry points take
+// the storage type of each tensor as a flag (0 = float, 1 = half); the plain entry points are the fp32 instantiations.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<_Float16>(const _Float16* p) {
+    const h16x4 h = *reinterpret_cast<const h16x4*>(p);
+    f32x4 v = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return v;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<_Float16>(_Float16* p, const f32x4 v) {
+    h16x4 h; h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+    *reinterpret_cast<h16x4*>(p) = h;
+}
+// dispatch on two storage flags: F(TI, TO)
+#define XMEM_DISPATCH_IO(in_half, out_half, F)                          \
+    do {                                                                \
+        if (in_half) { if (out_half) { F(_Float16, _Float16); } else { F(_Float16, float); } } \
+        else { if (out_half) { F(float, _Float16); } else { F(float, float); } }               \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // max pool 3x3 / stride 2 / pad 1  (implicit -inf padding like nn.MaxPool2d)
 // ---------------------------------------------------------------------------------------------
-__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename TI, typename TO>
+__global__ void maxpool3x3s2_kernel(const TI* __restrict__ in, TO* __restrict__ out,
                                     int B, int H, int W, int C, int Ho, int Wo) {
     const int C4 = C >> 2;
     const size_t total = (size_t)B * Ho * Wo * C4;
@@ -34,21 +59,26 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restr
             for (int dx = 0; dx < 3; ++dx) {
                 const int iw = ow * 2 - 1 + dx;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
+                const f32x4 v = ld4(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oh) * Wo + ow) * C + c4 * 4) = m;
+        st4(out + (((size_t)b * Ho + oh) * Wo + ow) * C + c4 * 4, m);
     }
 }
 
-extern "C" int xmem_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+extern "C" int xmem_maxpool3x3s2_t(const void* in, int in_half, void* out, int out_half, int B, int H, int W, int C, void* stream) {
     if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return XMEM_ERR_BAD_ARG;
     if (C % 4) return XMEM_ERR_UNSUPPORTED;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, out, B, H, W, C, Ho, Wo);
+#define F(TI, TO) hipLaunchKernelGGL((maxpool3x3s2_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI*)in, (TO*)out, B, H, W, C, Ho, Wo)
+    XMEM_DISPATCH_IO(in_half, out_half, F);
+#undef F
     return xmem_check_launch();
+}
+extern "C" int xmem_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+    return xmem_maxpool3x3s2_t(in, 0, out, 0, B, H, W, C, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -64,8 +94,9 @@ __device__ __forceinline__ void bilinear_src(int dst, float scale, int size, int
     l1 = src - (float)i0;
 }
 
-__global__ void upsample2x_add_kernel(const float* __restrict__ g, const float* __restrict__ skip,
-                                      float* __restrict__ out, int B, int h, int w, int C) {
+template <typename T>
+__global__ void upsample2x_add_kernel(const T* __restrict__ g, const T* __restrict__ skip,
+                                      T* __restrict__ out, int B, int h, int w, int C) {
     const int C4 = C >> 2, H = 2 * h, W = 2 * w;
     const size_t total = (size_t)B * H * W * C4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -78,33 +109,40 @@ __global__ void upsample2x_add_kernel(const float* __restrict__ g, const float* 
         bilinear_src(y, 0.5f, h, y0, y1, ly);
         bilinear_src(x, 0.5f, w, x0, x1, lx);
         const float hy = 1.f - ly, hx = 1.f - lx;
-        const float* gb = g + (size_t)b * h * w * C + c4 * 4;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y0 * w + x0) * C);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y0 * w + x1) * C);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y1 * w + x0) * C);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(gb + ((size_t)y1 * w + x1) * C);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(skip + ((size_t)y * W + x) * C + c4 * 4);
+        const T* gb = g + (size_t)b * h * w * C + c4 * 4;
+        const f32x4 v00 = ld4(gb + ((size_t)y0 * w + x0) * C);
+        const f32x4 v01 = ld4(gb + ((size_t)y0 * w + x1) * C);
+        const f32x4 v10 = ld4(gb + ((size_t)y1 * w + x0) * C);
+        const f32x4 v11 = ld4(gb + ((size_t)y1 * w + x1) * C);
+        const f32x4 s = ld4(skip + ((size_t)y * W + x) * C + c4 * 4);
         f32x4 o;
         o.x = s.x + (hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x));
         o.y = s.y + (hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y));
         o.z = s.z + (hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z));
         o.w = s.w + (hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w));
-        *reinterpret_cast<f32x4*>(out + (((size_t)b * H + y) * W + x) * C + c4 * 4) = o;
+        st4(out + (((size_t)b * H + y) * W + x) * C + c4 * 4, o);
     }
 }
 
-extern "C" int xmem_upsample2x_add(const float* g, const float* skip, float* out, int B, int h, int w, int C, void* stream) {
+extern "C" int xmem_upsample2x_add_t(const void* g, const void* skip, void* out, int half, int B, int h, int w, int C, void* stream) {
     if (!g || !skip || !out || B <= 0 || h <= 0 || w <= 0 || C <= 0) return XMEM_ERR_BAD_ARG;
     if (C % 4) return XMEM_ERR_UNSUPPORTED;
     const size_t total = (size_t)B * 4 * h * w * (C / 4);
-    hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, skip, out, B, h, w, C);
+    if (half) hipLaunchKernelGGL(upsample2x_add_kernel<_Float16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                 (const _Float16*)g, (const _Float16*)skip, (_Float16*)out, B, h, w, C);
+    else hipLaunchKernelGGL(upsample2x_add_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                            (const float*)g, (const float*)skip, (float*)out, B, h, w, C);
     return xmem_check_launch();
+}
+extern "C" int xmem_upsample2x_add(const float* g, const float* skip, float* out, int B, int h, int w, int C, void* stream) {
+    return xmem_upsample2x_add_t(g, skip, out, 0, B, h, w, C, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // area (average) downsample by integer ratio
 // ---------------------------------------------------------------------------------------------
-__global__ void area_down_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out, int ldout,
+template <typename TI, typename TO>
+__global__ void area_down_kernel(const TI* __restrict__ in, int ldin, TO* __restrict__ out, int ldout,
                                  int B, int H, int W, int C, int r) {
     const int Ho = H / r, Wo = W / r;
     const size_t total = (size_t)B * Ho * Wo * C;
@@ -118,23 +156,29 @@ __global__ void area_down_kernel(const float* __restrict__ in, int ldin, float* 
         float s = 0.f;
         for (int dy = 0; dy < r; ++dy)
             for (int dx = 0; dx < r; ++dx)
-                s += in[(((size_t)b * H + oh * r + dy) * W + ow * r + dx) * ldin + c];
-        out[(((size_t)b * Ho + oh) * Wo + ow) * ldout + c] = s * inv;
+                s += (float)in[(((size_t)b * H + oh * r + dy) * W + ow * r + dx) * ldin + c];
+        out[(((size_t)b * Ho + oh) * Wo + ow) * ldout + c] = (TO)(s * inv);
     }
 }
 
-extern "C" int xmem_area_downsample(const float* in, int ldin, float* out, int ldout, int B, int H, int W, int C, int r, void* stream) {
+extern "C" int xmem_area_downsample_t(const void* in, int in_half, int ldin, void* out, int out_half, int ldout, int B, int H, int W, int C, int r, void* stream) {
     if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0) return XMEM_ERR_BAD_ARG;
     if (H % r || W % r) return XMEM_ERR_UNSUPPORTED;
     const size_t total = (size_t)B * (H / r) * (W / r) * C;
-    hipLaunchKernelGGL(area_down_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, B, H, W, C, r);
+#define F(TI, TO) hipLaunchKernelGGL((area_down_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI*)in, ldin, (TO*)out, ldout, B, H, W, C, r)
+    XMEM_DISPATCH_IO(in_half, out_half, F);
+#undef F
     return xmem_check_launch();
+}
+extern "C" int xmem_area_downsample(const float* in, int ldin, float* out, int ldout, int B, int H, int W, int C, int r, void* stream) {
+    return xmem_area_downsample_t(in, 0, ldin, out, 0, ldout, B, H, W, C, r, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // channel-slice copy with object broadcast (concat builder)
 // ---------------------------------------------------------------------------------------------
-__global__ void copy_channels_kernel(const float* __restrict__ src, int ldsrc, int srcB, float* __restrict__ dst, int lddst,
+template <typename TI, typename TO>
+__global__ void copy_channels_kernel(const TI* __restrict__ src, int ldsrc, int srcB, TO* __restrict__ dst, int lddst,
                                      int B, int P, int C4) {
     const size_t total = (size_t)B * P * C4;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -142,17 +186,22 @@ __global__ void copy_channels_kernel(const float* __restrict__ src, int ldsrc, i
         size_t r = e / C4;
         const int pidx = (int)(r % P);
         const int b = (int)(r / P);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(b % srcB) * P + pidx) * ldsrc + c4 * 4);
-        *reinterpret_cast<f32x4*>(dst + ((size_t)b * P + pidx) * lddst + c4 * 4) = v;
+        const f32x4 v = ld4(src + ((size_t)(b % srcB) * P + pidx) * ldsrc + c4 * 4);
+        st4(dst + ((size_t)b * P + pidx) * lddst + c4 * 4, v);
     }
 }
 
-extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* dst, int lddst, int B, int P, int C, void* stream) {
+extern "C" int xmem_copy_channels_t(const void* src, int src_half, int ldsrc, int srcB, void* dst, int dst_half, int lddst, int B, int P, int C, void* stream) {
     if (!src || !dst || B <= 0 || P <= 0 || C <= 0 || srcB <= 0) return XMEM_ERR_BAD_ARG;
-    if (C % 4 || ldsrc % 4 || lddst % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return XMEM_ERR_UNSUPPORTED;
+    if (C % 4 || ldsrc % 4 || lddst % 4 || ((uintptr_t)src & (src_half ? 7 : 15)) || ((uintptr_t)dst & (dst_half ? 7 : 15))) return XMEM_ERR_UNSUPPORTED;
     const size_t total = (size_t)B * P * (C / 4);
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, ldsrc, srcB, dst, lddst, B, P, C / 4);
+#define F(TI, TO) hipLaunchKernelGGL((copy_channels_kernel<TI, TO>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI*)src, ldsrc, srcB, (TO*)dst, lddst, B, P, C / 4)
+    XMEM_DISPATCH_IO(src_half, dst_half, F);
+#undef F
     return xmem_check_launch();
+}
+extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* dst, int lddst, int B, int P, int C, void* stream) {
+    return xmem_copy_channels_t(src, 0, ldsrc, srcB, dst, 0, lddst, B, P, C, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -163,7 +212,8 @@ extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* 
 //   4. spatial+apply:  sg = sigmoid(conv7x7(comp)); out = g + (g*cscale)*sg             (2-3: kernel 2, 4: kernel 3; 16 pixels per workgroup)
 // ---------------------------------------------------------------------------------------------
 #define CBAM_PSPLIT 16
-__global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __restrict__ partial, int P, int C) {
+template <typename T>
+__global__ void cbam_channel_pool_kernel(const T* __restrict__ g, float* __restrict__ partial, int P, int C) {
     // block = 256 threads = 64 channels x 4 pixel stripes; grid = (C/64, B, CBAM_PSPLIT); partial [B][PSPLIT][2][C]
     __shared__ float ssum[4][64];
     __shared__ float smax[4][64];
@@ -173,9 +223,9 @@ __global__ void cbam_channel_pool_kernel(const float* __restrict__ g, float* __r
     const int p0 = ps * per, p1 = min(P, p0 + per);
     float s = 0.f, m = -INFINITY;
     if (c < C) {
-        const float* gb = g + (size_t)b * P * C + c;
+        const T* gb = g + (size_t)b * P * C + c;
         for (int pidx = p0 + stripe; pidx < p1; pidx += 4) {
-            const float v = gb[(size_t)pidx * C];
+            const float v = (float)gb[(size_t)pidx * C];
             s += v; m = fmaxf(m, v);
         }
     }
@@ -255,7 +305,8 @@ __device__ __forceinline__ void cbam_channel_scale(const float* __restrict__ par
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void cbam_compress_kernel(const float* __restrict__ g, const float* __restrict__ partial,
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_compress_kernel(const T* __restrict__ g, const float* __restrict__ partial,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             const float* __restrict__ w2, const float* __restrict__ b2,
                                                             float* __restrict__ cscale, float* __restrict__ comp, int P, int C, int Cr) {
@@ -268,10 +319,10 @@ __global__ __launch_bounds__(256) void cbam_compress_kernel(const float* __restr
     for (int i = wave; i < CBAM_PIX; i += 4) {                   // one wave per pixel
         const int pix = blockIdx.x * CBAM_PIX + i;
         if (pix >= P) break;
-        const float* gp = g + ((size_t)b * P + pix) * C;
+        const T* gp = g + ((size_t)b * P + pix) * C;
         float s = 0.f, m = -INFINITY;
         for (int c = lane * 4; c < C; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(gp + c);
+            const f32x4 v = ld4(gp + c);
             const f32x4 k = *reinterpret_cast<const f32x4*>(cs + c);
             const float a0 = v.x * k.x, a1 = v.y * k.y, a2 = v.z * k.z, a3 = v.w * k.w;
             s += (a0 + a1) + (a2 + a3);
@@ -282,9 +333,10 @@ __global__ __launch_bounds__(256) void cbam_compress_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void cbam_gate_apply_kernel(const float* __restrict__ g, const float* __restrict__ cscale,
+template <typename T>
+__global__ __launch_bounds__(256) void cbam_gate_apply_kernel(const T* __restrict__ g, const float* __restrict__ cscale,
                                                               const float* __restrict__ comp, const float* __restrict__ sw,
-                                                              const float* __restrict__ sb, float* __restrict__ out,
+                                                              const float* __restrict__ sb, T* __restrict__ out,
                                                               int H, int W, int C) {
     __shared__ float sg[CBAM_PIX];
     __shared__ float swl[98];
@@ -314,13 +366,13 @@ __global__ __launch_bounds__(256) void cbam_gate_apply_kernel(const float* __res
         const int pix = blockIdx.x * CBAM_PIX + i;
         if (pix >= P) break;
         const size_t off = ((size_t)b * P + pix) * C + c4 * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(g + off);
+        const f32x4 v = ld4(g + off);
         const f32x4 k = *reinterpret_cast<const f32x4*>(cscale + (size_t)b * C + c4 * 4);
         const float gsc = sg[i];
         f32x4 o;
         o.x = v.x + (v.x * k.x) * gsc; o.y = v.y + (v.y * k.y) * gsc;
         o.z = v.z + (v.z * k.z) * gsc; o.w = v.w + (v.w * k.w) * gsc;
-        *reinterpret_cast<f32x4*>(out + off) = o;
+        st4(out + off, o);
     }
 }
 
@@ -330,9 +382,18 @@ extern "C" size_t xmem_cbam_workspace_bytes(int B, int P, int C) {
            align_up((size_t)B * P * 2 * 4, 256) + align_up((size_t)B * P * 4, 256);
 }
 
-extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int W, int C,
-                                  const float* w1, const float* b1, const float* w2, const float* b2,
-                                  const float* sw, const float* sb, void* workspace, size_t workspace_bytes, void* stream) {
+template <typename T>
+static void cbam_launch(const T* g, T* out, int B, int H, int W, int C, int P, int Cr, const float* w1, const float* b1, const float* w2,
+                        const float* b2, const float* sw, const float* sb, float* pooled, float* cscale, float* comp, hipStream_t s) {
+    hipLaunchKernelGGL(cbam_channel_pool_kernel<T>, dim3(cdiv(C, 64), B, CBAM_PSPLIT), dim3(256), 0, s, g, pooled, P, C);
+    const size_t lds = ((size_t)3 * C + 2 * Cr) * sizeof(float);
+    hipLaunchKernelGGL(cbam_compress_kernel<T>, dim3(cdiv(P, CBAM_PIX), B), dim3(256), lds, s, g, pooled, w1, b1, w2, b2, cscale, comp, P, C, Cr);
+    hipLaunchKernelGGL(cbam_gate_apply_kernel<T>, dim3(cdiv(P, CBAM_PIX), B), dim3(256), 0, s, g, cscale, comp, sw, sb, out, H, W, C);
+}
+
+extern "C" int xmem_cbam_residual_t(const void* g, void* out, int half, int B, int H, int W, int C,
+                                    const float* w1, const float* b1, const float* w2, const float* b2,
+                                    const float* sw, const float* sb, void* workspace, size_t workspace_bytes, void* stream) {
     if (!g || !out || !w1 || !b1 || !w2 || !b2 || !sw || !sb || B <= 0 || H <= 0 || W <= 0 || C <= 0) return XMEM_ERR_BAD_ARG;
     if (C % 16) return XMEM_ERR_UNSUPPORTED;
     const int P = H * W, Cr = C / 16;
@@ -343,33 +404,41 @@ extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int 
     float* comp = (float*)ws;   ws += align_up((size_t)B * P * 2 * 4, 256);
     float* sgate = (float*)ws;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cbam_channel_pool_kernel, dim3(cdiv(C, 64), B, CBAM_PSPLIT), dim3(256), 0, s, g, pooled, P, C);
     (void)sgate;
-    const size_t lds = ((size_t)3 * C + 2 * Cr) * sizeof(float);
-    hipLaunchKernelGGL(cbam_compress_kernel, dim3(cdiv(P, CBAM_PIX), B), dim3(256), lds, s, g, pooled, w1, b1, w2, b2, cscale, comp, P, C, Cr);
-    hipLaunchKernelGGL(cbam_gate_apply_kernel, dim3(cdiv(P, CBAM_PIX), B), dim3(256), 0, s, g, cscale, comp, sw, sb, out, H, W, C);
+    if (half) cbam_launch<_Float16>((const _Float16*)g, (_Float16*)out, B, H, W, C, P, Cr, w1, b1, w2, b2, sw, sb, pooled, cscale, comp, s);
+    else cbam_launch<float>((const float*)g, (float*)out, B, H, W, C, P, Cr, w1, b1, w2, b2, sw, sb, pooled, cscale, comp, s);
     return xmem_check_launch();
+}
+extern "C" int xmem_cbam_residual(const float* g, float* out, int B, int H, int W, int C,
+                                  const float* w1, const float* b1, const float* w2, const float* b2,
+                                  const float* sw, const float* sb, void* workspace, size_t workspace_bytes, void* stream) {
+    return xmem_cbam_residual_t(g, out, 0, B, H, W, C, w1, b1, w2, b2, sw, sb, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // GRU-like gate, add3
 // ---------------------------------------------------------------------------------------------
-__global__ void gru_gate_kernel(const float* __restrict__ values, const float* h, float* nh,      // nh may alias h (in-place state update)
+template <typename T>
+__global__ void gru_gate_kernel(const T* __restrict__ values, const float* h, float* nh,      // nh may alias h (in-place state update)
                                 size_t BP, int Ch) {
     const size_t total = BP * Ch;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t pix = e / Ch; const int c = (int)(e - pix * Ch);
-        const float* v = values + pix * 3 * Ch;
-        const float f = sigmoidf_(v[c]), u = sigmoidf_(v[Ch + c]), n = tanhf(v[2 * Ch + c]);
+        const T* v = values + pix * 3 * Ch;
+        const float f = sigmoidf_((float)v[c]), u = sigmoidf_((float)v[Ch + c]), n = tanhf((float)v[2 * Ch + c]);
         nh[e] = f * h[e] * (1.f - u) + u * n;
     }
 }
 
-extern "C" int xmem_gru_gate(const float* values, const float* h, float* new_h, int B, int P, int Ch, void* stream) {
+extern "C" int xmem_gru_gate_t(const void* values, int values_half, const float* h, float* new_h, int B, int P, int Ch, void* stream) {
     if (!values || !h || !new_h || B <= 0 || P <= 0 || Ch <= 0) return XMEM_ERR_BAD_ARG;
     const size_t BP = (size_t)B * P;
-    hipLaunchKernelGGL(gru_gate_kernel, dim3(grid_for(BP * Ch)), dim3(256), 0, (hipStream_t)stream, values, h, new_h, BP, Ch);
+    if (values_half) hipLaunchKernelGGL(gru_gate_kernel<_Float16>, dim3(grid_for(BP * Ch)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)values, h, new_h, BP, Ch);
+    else hipLaunchKernelGGL(gru_gate_kernel<float>, dim3(grid_for(BP * Ch)), dim3(256), 0, (hipStream_t)stream, (const float*)values, h, new_h, BP, Ch);
     return xmem_check_launch();
+}
+extern "C" int xmem_gru_gate(const float* values, const float* h, float* new_h, int B, int P, int Ch, void* stream) {
+    return xmem_gru_gate_t(values, 0, h, new_h, B, P, Ch, stream);
 }
 
 __global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
