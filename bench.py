@@ -48,10 +48,13 @@ CK, CV, TOPK = 64, 512, 30
 BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
 
 PRECISION_LABEL = {'fp32': '',
-                   'fp16': ' [REDUCED-PRECISION MODE fp16: not the headline metric]',
+                   'fp16': ' [FP16 LOOP (half activations + half-operand convolutions, fp32 accumulate; the reference\'s autocast mode): not the headline metric]',
+                   'fp16w': ' [EXPERIMENT fp16w (fp16 Winograd-F(2x2) operands only): not the headline metric]',
                    'fp32x': ' [SPLIT-OPERAND EXPERIMENT fp32x: separately reported, not the headline metric]'}
 PRECISION_DTYPE = {'fp32': 'f32',
-                   'fp16': 'f16 Winograd-domain conv operands, f32 accumulate; everything else f32',
+                   'fp16': 'f16 activations in HBM and f16 conv operands (direct implicit GEMM on v_mfma_f32_32x32x16_f16), f32 accumulate and epilogue; '
+                           'stems, keys, memory, readout weights, GRU state, logits, probabilities f32; permanent-memory preload f32',
+                   'fp16w': 'f16 Winograd-domain conv operands, f32 accumulate; everything else f32',
                    'fp32x': 'f32 carried as f16 pairs (hi + lo) in the conv GEMMs: four partial products on the fp16 MFMA, f32 accumulate; '
                             'tensors, memory readout and everything else f32'}
 
@@ -457,6 +460,25 @@ def run_traced_child(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def run_mode_child(args, mode):
+    """frames/s of the same workload in an opt-in precision mode (bench.py --precision <mode> as a child process, no CPU baseline /
+    trace / plain pass), or {'error': ...}."""
+    steps = min(args.steps, 120)
+    cmd = [sys.executable, os.path.abspath(__file__), '--precision', mode, '--steps', str(steps), '--warmup', str(args.warmup),
+           '--workload', args.workload, '--key-batch', str(args.key_batch), '--no-cpu-baseline', '--no-kernel-trace', '--plain-steps', '0',
+           '--no-extra-modes']
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        j = json.loads(p.stdout.strip().splitlines()[-1])
+        return dict(value=j['value'], unit='frames/s', steps=steps, dtype=j['dtype'],
+                    note='opt-in mode, separately reported, not the headline: ' + PRECISION_LABEL[mode].strip())
+    except Exception as e:
+        return dict(error=f'{type(e).__name__}: {e}')
+
+
 def committed_pmc(workload, precision='fp32'):
     """HBM-side bytes per frame from the committed PMC passes (profiles/r*_pmc_per_frame*.json), quoted ONLY when they
     were recorded for exactly this build of the kernels (source digest match) - otherwise None, never a stale number."""
@@ -601,7 +623,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='b32', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline at its best thread count')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16', 'fp32x'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16', 'fp16w', 'fp32x'],
                     help='fp16 = the opt-in reduced-precision mode (Winograd-domain operands in fp16, fp32 accumulation; SURVEY 8f-4); '
                          'fp32x = the split-operand experiment (every fp32 GEMM operand carried as two halfs, four partial products on the '
                          'fp16 MFMA, fp32 accumulation: fp32-class results).  Both are reported under their own metric label, never the headline')
@@ -614,6 +636,7 @@ def parse_args(argv=None):
     ap.add_argument('--trace-timeout', type=int, default=420)
     ap.add_argument('--keep-trace', default=None, help='directory to keep the child\'s kernel_trace.csv in')
     ap.add_argument('--traced-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-extra-modes', action='store_true', help='skip the child runs that add value_fp32x / value_fp16_loop to the default line')
     ap.add_argument('--dist-backend', default='gloo', help='control-plane backend for the timing barrier / reductions '
                     '(nccl = RCCL; the data path has no collective)')
     return ap.parse_args(argv)
@@ -841,6 +864,10 @@ def main():
                 line['cpu_baseline'] = cpu
                 line['parity'] = parity
                 line['speedup_vs_cpu'] = fps / cpu['value']
+        if world == 1 and args.workload == 'b32' and args.precision == 'fp32' and not args.no_extra_modes and not args.no_prefetch:
+            # the opt-in modes on the same workload, each as its own labelled key (never the headline): child copies of this command
+            for mode, label in (('fp32x', 'value_fp32x'), ('fp16', 'value_fp16_loop')):
+                line[label] = run_mode_child(args, mode)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -161,6 +161,19 @@ int xmem_gru_gate(const float* values, const float* h, float* new_h, int B, int 
 /* y = a + b + c elementwise (n floats), HiddenUpdater sum modules.py:56-57 */
 int xmem_add3(const float* a, const float* b, const float* c, float* y, size_t n, void* stream);
 
+/* STORAGE-TYPED VARIANTS (the fp16 loop, config['precision'] = 'fp16': activations live in HBM as IEEE halfs, as the tensors of
+ * the reference's autocast frame loop do, inference/run_on_video.py:76).  Same kernels, same fp32 arithmetic; `*_half` flags give
+ * the storage type of each tensor (0 = float, 1 = half; leading dimensions count elements of that type); a stored value is
+ * rounded once, to nearest even.  The plain functions above are the all-float instantiations.  The GRU state stays fp32. */
+int xmem_maxpool3x3s2_t(const void* in, int in_half, void* out, int out_half, int B, int H, int W, int C, void* stream);
+int xmem_upsample2x_add_t(const void* g, const void* skip, void* out, int half, int B, int h, int w, int C, void* stream);
+int xmem_area_downsample_t(const void* in, int in_half, int ldin, void* out, int out_half, int ldout, int B, int H, int W, int C, int r, void* stream);
+int xmem_copy_channels_t(const void* src, int src_half, int ldsrc, int srcB, void* dst, int dst_half, int lddst, int B, int P, int C, void* stream);
+int xmem_cbam_residual_t(const void* g, void* out, int half, int B, int H, int W, int C,
+                         const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* sw, const float* sb, void* workspace, size_t workspace_bytes, void* stream);
+int xmem_gru_gate_t(const void* values, int values_half, const float* h, float* new_h, int B, int P, int Ch, void* stream);
+
 /* image [3][H][W] (NCHW, unpadded) -> [Hp][Wp][4] NHWC, zero padded as pad_divide_by
  * (util/tensor_util.py:47-61): left/top pads lw, lh; 4th channel zero. */
 int xmem_pack_image(const float* img, float* out, int H, int W, int Hp, int Wp, int lh, int lw, void* stream);
@@ -286,6 +299,11 @@ typedef struct {
 int xmem_readout_sparse(const xmem_value_segment* vsegs_host, int n_obj, int n_seg,
                         const float* w, const int32_t* idx, int HW, int top_k, int Cv,
                         float* out, int ldout, size_t obj_stride, void* stream);
+/* The same readout with the output stored as IEEE halfs when out_half = 1 (ldout / obj_stride then count halfs): the fp16 loop's
+ * decoder input.  Memory values stay fp32 (the permanent memory is preloaded in fp32, inference/run_on_video.py:59-66). */
+int xmem_readout_sparse_t(const xmem_value_segment* vsegs_host, int n_obj, int n_seg,
+                          const float* w, const int32_t* idx, int HW, int top_k, int Cv,
+                          void* out, int out_half, int ldout, size_t obj_stride, void* stream);
 
 /* Dense similarity (no top-k): sim[n][p], n over one segment, p over P queries.  Used by the long-term
  * consolidation (memory_manager.py:368) where the softmax runs over the candidate axis. out [P][n] (query-major). */

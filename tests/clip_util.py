@@ -50,7 +50,19 @@ def _sizes(m):
     return (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size)
 
 
+_ORACLE_CACHE = {}
+
+
 def run_oracle(ref_net, clip, threads):
+    """(argmax masks, probabilities, memory sizes) per frame of the oracle at `threads` torch threads; cached per (clip, threads)
+    within a test session (the oracle is deterministic at a fixed thread count)."""
+    ck = (clip.name, threads)
+    if ck not in _ORACLE_CACHE:
+        _ORACLE_CACHE[ck] = _run_oracle(ref_net, clip, threads)
+    return _ORACLE_CACHE[ck]
+
+
+def _run_oracle(ref_net, clip, threads):
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:

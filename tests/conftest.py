@@ -54,12 +54,17 @@ def device():
 
 
 @pytest.fixture(scope='session')
-def hip_net(synth_sd):
+def hip_net(request, synth_sd):
+    """The HIP network in the default fp32 mode; `@pytest.mark.parametrize('hip_net', ['fp32', 'fp32x'], indirect=True)` runs a test
+    in the opt-in split-operand mode as well (same gates: it is fp32-class)."""
     from xmem2_amd.network import XMem
-    cfg = {'key_dim': 64, 'value_dim': 512, 'hidden_dim': 64}
+    cfg = {'key_dim': 64, 'value_dim': 512, 'hidden_dim': 64, 'precision': getattr(request, 'param', 'fp32')}
     net = XMem(cfg, None).to('cuda').eval()
     net.load_weights(synth_sd)
     return net
+
+
+BOTH_FP32_CLASS_MODES = pytest.mark.parametrize('hip_net', ['fp32', 'fp32x'], indirect=True)
 
 
 @pytest.fixture(scope='session')

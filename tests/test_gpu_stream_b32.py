@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
+@pytest.mark.parametrize('hip_net', ['fp32', 'fp32x'], indirect=True)
 def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref_net):
     from conftest import base_config
     from xmem2_amd.inference_core import InferenceCore

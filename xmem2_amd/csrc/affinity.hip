@@ -1331,6 +1331,7 @@ struct ReadoutArgs {
     float* out; int ldout; size_t obj_stride;
 };
 
+template <bool OUT_HALF>
 __global__ void readout_sparse_kernel(ReadoutArgs p) {
     // one workgroup per (query, object): the k row pointers are resolved once, then the rows stream in batches of six
     // independent 16-byte loads per thread (the gather is latency-bound: k * C_v * 4 B = 60 KB per query and object)
@@ -1363,12 +1364,19 @@ __global__ void readout_sparse_kernel(ReadoutArgs p) {
             const float ws = wsm[s];
             acc.x += ws * v.x; acc.y += ws * v.y; acc.z += ws * v.z; acc.w += ws * v.w;
         }
-        *reinterpret_cast<f32x4*>(p.out + (size_t)obj * p.obj_stride + (size_t)q * p.ldout + c4 * 4) = acc;
+        if (OUT_HALF) {                                // fp16 loop: the readout lands in the decoder's half-typed input (strides count halfs)
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 h; h.x = (_Float16)acc.x; h.y = (_Float16)acc.y; h.z = (_Float16)acc.z; h.w = (_Float16)acc.w;
+            *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(p.out) + (size_t)obj * p.obj_stride + (size_t)q * p.ldout + c4 * 4) = h;
+        } else {
+            *reinterpret_cast<f32x4*>(p.out + (size_t)obj * p.obj_stride + (size_t)q * p.ldout + c4 * 4) = acc;
+        }
     }
 }
 
-extern "C" int xmem_readout_sparse(const xmem_value_segment* vsegs, int n_obj, int n_seg, const float* w, const int32_t* idx,
-                                   int HW, int top_k, int Cv, float* out, int ldout, size_t obj_stride, void* stream) {
+extern "C" int xmem_readout_sparse_t(const xmem_value_segment* vsegs, int n_obj, int n_seg, const float* w, const int32_t* idx,
+                                     int HW, int top_k, int Cv, void* out_v, int out_half, int ldout, size_t obj_stride, void* stream) {
+    float* out = reinterpret_cast<float*>(out_v);
     if (!vsegs || n_obj <= 0 || n_seg <= 0 || n_seg > XMEM_MAX_SEGMENTS || !w || !idx || !out || HW <= 0 || top_k <= 0) return XMEM_ERR_BAD_ARG;
     if (Cv % 4 || ldout % 4 || ldout < Cv || obj_stride % 4) return XMEM_ERR_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1384,13 +1392,19 @@ extern "C" int xmem_readout_sparse(const xmem_value_segment* vsegs, int n_obj, i
                 a.val[o * n_seg + sg] = v.value;
             }
         a.n_obj = no; a.n_seg = n_seg; a.w = w; a.idx = idx; a.HW = HW; a.top_k = top_k; a.Cv = Cv;
-        a.out = out + (size_t)o0 * obj_stride; a.ldout = ldout; a.obj_stride = obj_stride;
+        a.out = out_half ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(out_v) + (size_t)o0 * obj_stride) : out + (size_t)o0 * obj_stride;
+        a.ldout = ldout; a.obj_stride = obj_stride;
         int threads = Cv / 4; if (threads > 256) threads = 256; threads = (threads + 63) / 64 * 64;
-        hipLaunchKernelGGL(readout_sparse_kernel, dim3(HW, no), dim3(threads), 0, s, a);
+        if (out_half) hipLaunchKernelGGL(readout_sparse_kernel<true>, dim3(HW, no), dim3(threads), 0, s, a);
+        else hipLaunchKernelGGL(readout_sparse_kernel<false>, dim3(HW, no), dim3(threads), 0, s, a);
         int rc = xmem_check_launch();
         if (rc != XMEM_OK) return rc;
     }
     return XMEM_OK;
+}
+extern "C" int xmem_readout_sparse(const xmem_value_segment* vsegs, int n_obj, int n_seg, const float* w, const int32_t* idx,
+                                   int HW, int top_k, int Cv, float* out, int ldout, size_t obj_stride, void* stream) {
+    return xmem_readout_sparse_t(vsegs, n_obj, n_seg, w, idx, HW, top_k, Cv, out, 0, ldout, obj_stride, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -26,6 +26,11 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def _padc(n):
+    """channel padding of a buffer the network allocates: 4 floats or (fp16 loop) 8 halfs = one 16-byte operand chunk"""
+    return (n + 7) // 8 * 8 if ops.act_dtype() == torch.float16 else _pad4(n)
+
+
 class XMem:
     def __init__(self, config, model_path=None, map_location=None, pretrained_key_encoder=True, pretrained_value_encoder=True):
         """Same signature as model/network.py:18.  `pretrained_*` are accepted for compatibility; torchvision
@@ -37,8 +42,9 @@ class XMem:
         self._cbam = {}
         # launch-bound stages (61 convolutions + ~40 small kernels per frame) are replayed as HIP graphs
         self.use_graphs = os.environ.get('XMEM_HIP_GRAPHS', '1') != '0'
-        # 'fp32' (default: the parity contract) | 'fp16' (opt-in: Winograd-domain operands in fp16, fp32 accumulation -
-        # the counterpart of the reference's autocast loop; the permanent-memory preload stays fp32 as in run_on_video.py:66)
+        # 'fp32' (default: the parity contract) | 'fp16' (opt-in: the fp16 loop - half activations in HBM, half-operand convolutions
+        # on the fp16 MFMA with fp32 accumulation: the counterpart of the reference's autocast loop, run_on_video.py:76; the
+        # permanent-memory preload stays fp32 as in run_on_video.py:59-66) | 'fp16w' / 'fp32x' (experiments, ops.PRECISIONS)
         self.precision = config.get('precision', os.environ.get('XMEM_PRECISION', 'fp32'))
         if self.precision not in ops.PRECISIONS:
             raise ValueError(f"config['precision'] must be one of {ops.PRECISIONS}, got {self.precision!r}")
@@ -402,8 +408,8 @@ class XMem:
 
     def _encode_key_eager(self, image4, need_sk, need_ek, overlap=False, inline_skips=False):
         W = self._w
-        x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)
-        x = ops.maxpool3x3s2(x)
+        x = ops.conv2d(image4, W['key_encoder.conv1'], relu_out=True)       # the stem reads the fp32 image in every mode
+        x = ops.maxpool3x3s2(x, out_dtype=ops.act_dtype())                # fp16 loop: activations become halfs here
         f4 = self._stage(x, 'key_encoder.res2', 3, self._bottleneck)
         skip4 = skip8 = None
         main = torch.cuda.current_stream()
@@ -422,7 +428,7 @@ class XMem:
         B, h, w, _ = f16.shape
         ld = _pad4(2 * self.key_dim + 1)
         proj = torch.empty((B, h, w, ld), dtype=torch.float32, device=f16.device)
-        ops.conv2d(f16, W['key_proj'], out=proj, out_ld=ld)
+        ops.conv2d(f16, W['key_proj'], out=proj, out_ld=ld, out_dtype=torch.float32)     # keys / shrinkage / selection are fp32 in every mode
         key, shr, sel = ops.key_post(proj, self.key_dim, need_sk, need_ek)
         if inline_skips:                      # same stream: f8 / f4 only depend on the image (model/modules.py:186,231-232)
             extras = (ops.conv2d(f8, W['decoder.up_16_8.skip_conv']), ops.conv2d(f4, W['decoder.up_8_4.skip_conv']))
@@ -451,19 +457,20 @@ class XMem:
     def _encode_value_eager(self, image4, f16, hidden, masks, is_deep_update):
         W = self._w
         x = ops.pack_value_input(image4, masks)
+        act = ops.act_dtype()
         g = ops.conv2d(x, W['value_encoder.conv1'], relu_out=True)     # relu and max-pool commute (modules.py:137-138)
-        g = ops.maxpool3x3s2(g)
+        g = ops.maxpool3x3s2(g, out_dtype=act)
         g = self._stage(g, 'value_encoder.layer1', 2, self._basic)
         g = self._stage(g, 'value_encoder.layer2', 2, self._basic)
         g = self._stage(g, 'value_encoder.layer3', 2, self._basic)
         K, h, w, cg = g.shape
-        cat = torch.empty((K, h, w, f16.shape[3] + cg), dtype=torch.float32, device=g.device)
+        cat = torch.empty((K, h, w, f16.shape[3] + cg), dtype=act, device=g.device)
         if not self._shares_x('value_encoder.fuser', K):
             ops.copy_channels(f16, cat, 0)
         ops.copy_channels(g, cat, f16.shape[3])
         value = self._fusion(cat, 'value_encoder.fuser', x=f16)
         if is_deep_update and self.hidden_dim > 0:
-            cat2 = torch.empty((K, h, w, self.value_dim + self.hidden_dim), dtype=torch.float32, device=g.device)
+            cat2 = torch.empty((K, h, w, self.value_dim + self.hidden_dim), dtype=act, device=g.device)
             ops.copy_channels(value, cat2, 0)
             ops.copy_channels(hidden, cat2, self.value_dim)
             values = ops.conv2d(cat2, W['value_encoder.hidden_reinforce.transform'])
@@ -499,6 +506,7 @@ class XMem:
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
         Once the matching decoder stage is captured this is its static input buffer (no copy before the replay)."""
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
+        prec = self._call_precision or self.precision
         if self.use_graphs and not ops.eager_only():
             for k, st in self._stages.items():
                 if k[0] != 'segment' or k[2] != (self._call_precision or self.precision) or k[1][-2] != slot or k[1][-1] != owner \
@@ -507,15 +515,15 @@ class XMem:
                 if (h_out is not None and k[1][2] != bool(h_out)) or (has_skips is not None and k[1][3] != bool(has_skips)):
                     continue
                 return st[1][3]
-        return torch.empty(shape, dtype=torch.float32, device=device)
+        return torch.empty(shape, dtype=torch.float16 if prec == 'fp16' else torch.float32, device=device)
 
-    def _zero_scratch(self, shape, device):
+    def _zero_scratch(self, shape, device, dtype=torch.float32):
         """Persistent zero-initialised buffer (allocated outside any capture): kernels overwrite only its data channels, the
         padding channels stay zero - no per-frame fill kernel."""
-        key = (tuple(shape), str(device))
+        key = (tuple(shape), str(device), dtype)
         buf = self._zeros.get(key)
         if buf is None:
-            buf = torch.zeros(shape, dtype=torch.float32, device=device)
+            buf = torch.zeros(shape, dtype=dtype, device=device)
             self._zeros[key] = buf
         return buf
 
@@ -529,7 +537,9 @@ class XMem:
         g4d = None
         if h_out and self.hidden_dim > 0:
             c4 = self._w['decoder.pred'].cin
-            g4d = self._zero_scratch((K, h, w, _pad4(c4 + 1)), cat16.device)
+            half = (self._call_precision or self.precision) == 'fp16'
+            g4d = self._zero_scratch((K, h, w, (c4 + 1 + 7) // 8 * 8 if half else _pad4(c4 + 1)), cat16.device,
+                                     torch.float16 if half else torch.float32)
         if skips is not None and len(skips) >= 4:
             out = self._run_stage('segment', (tuple(out_hw), tuple(pad_tl), bool(h_out), True, slot, owner),
                                   [f16, f8, f4, cat16, hidden, skips[0], skips[1], skips[2], skips[3]],
@@ -565,18 +575,18 @@ class XMem:
         g8 = self._group_res(ops.upsample2x_add(g16, skip8), 'decoder.up_16_8.out_conv')
         skip4 = skips[1] if skips is not None else ops.conv2d(f4, W['decoder.up_8_4.skip_conv'])
         g4 = self._group_res(ops.upsample2x_add(g8, skip4), 'decoder.up_8_4.out_conv')
-        logits = ops.conv2d(g4, W['decoder.pred'], relu_in=True)          # [K,4h,4w,1]
+        logits = ops.conv2d(g4, W['decoder.pred'], relu_in=True, out_dtype=torch.float32)          # [K,4h,4w,1], fp32 in every mode
         new_hidden = None
         if h_out and hd > 0:
             c4 = g4.shape[3]
             if g4d is None:
-                g4d = self._zero_scratch((K, h, w, _pad4(c4 + 1)), g4.device)
+                g4d = self._zero_scratch((K, h, w, _padc(c4 + 1)), g4.device, ops.act_dtype())
             ops.area_downsample(g4, 4, out=g4d, out_ld=g4d.shape[3])
             ops.area_downsample(logits, 4, out=g4d, out_ld=g4d.shape[3], out_off=c4)
             g8d = ops.area_downsample(g8, 2)
             t = ops.conv2d(g16, W['decoder.hidden_update.g16_conv'])
             t = ops.conv2d(g8d, W['decoder.hidden_update.g8_conv'], res=t)
-            cat = torch.empty((K, h, w, t.shape[3] + hd), dtype=torch.float32, device=g4.device)
+            cat = torch.empty((K, h, w, t.shape[3] + hd), dtype=ops.act_dtype(), device=g4.device)
             ops.conv2d(g4d, W['decoder.hidden_update.g4_conv'], res=t, out=cat, out_ld=cat.shape[3])
             ops.copy_channels(hidden, cat, t.shape[3])
             values = ops.conv2d(cat, W['decoder.hidden_update.transform'])

@@ -124,22 +124,37 @@ def workspace(nbytes, device, tag='default'):
     return buf
 
 
-def _req(t, name):
+def _req(t, name, half_ok=False):
     if not t.is_cuda:
         raise RuntimeError(f'{name}: expected a CUDA (HIP) tensor - xmem2_amd has no CPU path')
-    if t.dtype != torch.float32:
-        raise RuntimeError(f'{name}: expected float32')
+    if t.dtype != torch.float32 and not (half_ok and t.dtype == torch.float16):
+        raise RuntimeError(f'{name}: expected float32' + (' or float16' if half_ok else ''))
     return t
+
+
+def _h(t):
+    """storage flag of the `_t` entry points: 1 = IEEE half, 0 = float"""
+    return int(t.dtype == torch.float16)
 
 
 # Arithmetic mode of the 3x3 / stride-1 convolutions.  'fp32' (default, the parity contract) or 'fp16': OPT-IN reduced
 # precision - the Winograd-domain operands are rounded to fp16 and multiplied on the fp16 MFMA with fp32 accumulation (the
 # counterpart of the reference's autocast loop, inference/run_on_video.py:76).  Set per call tree by XMem (`precision`).
 _PRECISION = 'fp32'
-PRECISIONS = ('fp32', 'fp16', 'fp32x')
+PRECISIONS = ('fp32', 'fp16', 'fp16w', 'fp32x')
+# 'fp16' (opt-in): THE FP16 LOOP - the counterpart of the reference's GPU mode (torch.cuda.amp.autocast around the frame loop,
+# inference/run_on_video.py:76; fp32 preload :59-66): activations are IEEE halfs in HBM, every convolution contracts half
+# operands on v_mfma_f32_32x32x16_f16 in the direct form with fp32 accumulation and an fp32 epilogue, elementwise kernels
+# compute in fp32 on half storage; stems, key projection output, memory (keys, values, readout weights), GRU state, logits and
+# probabilities stay fp32.  'fp16w' is round 2's experiment (only the F(2x2) Winograd-domain operands in fp16), kept runnable.
 # 'fp32x' (opt-in, separately reported): SPLIT-OPERAND arithmetic - every fp32 operand of every GEMM-shaped convolution is
 # carried as two halfs (x = hi + lo, <= 2^-21 relative) and the four partial products run on v_mfma_f32_32x32x16_f16 with fp32
 # accumulation (csrc/conv_mfma.hip, SPLIT kernels).  Same tensors, same bytes, fp32-class results; 1/4 of the fp32 MFMA cycles.
+
+
+def act_dtype():
+    """Storage type of the activations the network allocates in the current mode: halfs in the fp16 loop, floats otherwise."""
+    return torch.float16 if _PRECISION == 'fp16' else torch.float32
 
 
 class precision:
@@ -160,7 +175,7 @@ class precision:
 class ConvWeights:
     """Device-resident convolution parameters in kernel layout: w [Cout][KH][KW][Cin_pad], scale, shift."""
     __slots__ = ('w', 'scale', 'shift', 'cout', 'cin', 'kh', 'kw', 'stride', 'pad', 'cin_true', 'wu', 'wu_f16', 'wu4',
-                 'sp_shift', 'scale_sp', 'w_sp', 'wu_sp', 'wu4_sp')
+                 'sp_shift', 'scale_sp', 'w_sp', 'wu_sp', 'wu4_sp', 'w_h')
 
     def __init__(self, w, scale, shift, stride, pad, cin_true=None, winograd=True):
         self.w, self.scale, self.shift = w, scale, shift
@@ -172,12 +187,23 @@ class ConvWeights:
         self.wu4 = None                  # F(4x4,3x3) operand, built on first use (only the large layers take that path)
         self.sp_shift = None             # 'fp32x' mode only: split operands (built on first use), see ensure_split
         self.scale_sp = self.w_sp = self.wu_sp = self.wu4_sp = None
+        self.w_h = None                  # 'fp16' loop: the weights as halfs [Cout][KH][KW][Cin pad 8], built on first use (half())
         if winograd and self.kh == 3 and self.kw == 3 and stride == 1 and pad == 1 and self.cin % 32 == 0 \
                 and self.cout % 4 == 0 and self.cout >= 32:
             self.wu = winograd_weights(w)
             if self.cin % 64 == 0:
                 self.wu_f16 = self.wu.to(torch.float16).contiguous()      # reduced-precision mode only
 
+
+    def half(self):
+        """[Cout][KH][KW][Cin'] IEEE halfs, Cin' = Cin padded to a multiple of 8 with zero channels (a 16-byte operand chunk is 8
+        halfs); rounded once to nearest even, as autocast casts fp32 weights."""
+        if self.w_h is None:
+            w = self.w
+            if w.shape[3] % 8:
+                w = torch.nn.functional.pad(w, (0, 8 - w.shape[3] % 8))
+            self.w_h = w.to(torch.float16).contiguous()
+        return self.w_h
 
     def ensure_split(self):
         """Split-operand forms of the weights for the 'fp32x' mode: every array the kernels may contract (direct, F(2x2), F(4x4))
@@ -431,11 +457,95 @@ def conv_executed_mfma_flops(B, Ho, Wo, cin, cout, kh, kw, stride, pad, plan_til
     return npos * 2.0 * up(tiles, tile[0]) * up(cout, tile[1]) * up(cin, 32)
 
 
+_PLAN_FILE_H = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_plans_fp16.json')   # measured with the half kernels
+_plans_h = None
+_tuned_now_h = {}
+
+
+def _conv2d_half(lib, x, cw, out, out_ld, res, relu_in, relu_out, in_ld, cin, plan, res_broadcast, out_dtype):
+    """The fp16 loop's convolution: x [B,H,W,C] halfs (pixel stride in_ld halfs), half weights, direct implicit GEMM on the fp16
+    MFMA, fp32 accumulation + epilogue; output (and residual) halfs, or float32 with out_dtype=torch.float32 (key projection,
+    mask head).  Input channels beyond the layer's own (a buffer padded to a multiple of 8) must be zero: the half weights are
+    zero there."""
+    global _plans_h
+    B, H, W = x.shape[0], x.shape[1], x.shape[2]
+    ldin = in_ld if in_ld is not None else x.shape[3]
+    wh = cw.half()
+    cin_h = wh.shape[3]                                   # the layer's Cin padded to 8
+    cin = cin if cin is not None else cin_h
+    if cin != cin_h and cin != cw.cin:
+        raise RuntimeError(f'conv2d (half): weight expects Cin={cw.cin} (padded {cin_h}), got {cin}')
+    if cin_h > ldin:
+        raise RuntimeError(f'conv2d (half): the input buffer has {ldin} channels per pixel, the layer reads {cin_h} (pad to a multiple of 8)')
+    Ho = (H + 2 * cw.pad - cw.kh) // cw.stride + 1
+    Wo = (W + 2 * cw.pad - cw.kw) // cw.stride + 1
+    odt = out_dtype if out_dtype is not None else (out.dtype if out is not None else torch.float16)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cw.cout), dtype=odt, device=x.device)
+        out_ld = cw.cout
+    elif out_ld is None:
+        out_ld = out.shape[-1]
+    if out.dtype != odt:
+        raise RuntimeError('conv2d (half): out buffer dtype does not match out_dtype')
+    if res is not None and res.dtype != out.dtype:
+        raise RuntimeError('conv2d (half): the residual must have the output storage type')
+    d = ConvDesc()
+    d.inp = x.data_ptr(); d.B, d.H, d.W, d.Cin, d.ldin = B, H, W, cin_h, ldin
+    d.w = cw.w.data_ptr(); d.Cout, d.KH, d.KW, d.stride, d.pad = cw.cout, cw.kh, cw.kw, cw.stride, cw.pad
+    d.scale = cw.scale.data_ptr(); d.shift = cw.shift.data_ptr()
+    d.res = res.data_ptr() if res is not None else None
+    d.ldres = res.shape[-1] if res is not None else 0
+    d.res_broadcast = int(bool(res_broadcast and res is not None))
+    d.out = out.data_ptr(); d.ldout = out_ld
+    d.relu_in, d.relu_out = int(relu_in), int(relu_out)
+    d.in_half, d.out_half, d.w_half = 1, int(out.dtype == torch.float16), wh.data_ptr()
+    key = f'h{B}x{H}x{W}x{cin_h}/{ldin}->{cw.cout}/{out_ld} k{cw.kh}s{cw.stride}p{cw.pad} r{int(res is not None)}{int(relu_in)}{int(relu_out)}o{d.out_half}'
+    if plan is None:
+        if _plans_h is None:
+            _plans_h = _read_plan_file(_PLAN_FILE_H)
+        plan = _plans_h.get(key) or _tuned_now_h.get(key)
+        if plan is None:
+            plan = (0, 0)
+            if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
+                best, best_t = (0, 0), None
+                for tile in (1, 2, 3):
+                    for sk in (1, 2, 4, 8):
+                        t = _time_plan(lib, d, x.device, (tile, sk), reps=8)
+                        if t is not None and (best_t is None or t < best_t):
+                            best, best_t = (tile, sk), t
+                plan = best
+            _tuned_now_h[key] = plan
+    d.plan_tile, d.plan_splitk = plan
+    need = lib.xmem_conv2d_workspace_bytes(C.byref(d))
+    ws = workspace(need, x.device, 'conv') if need else None
+    check(lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()))
+    if RECORD is not None:
+        RECORD.append(('conv', key, 2.0 * B * Ho * Wo * cw.cout * cw.kh * cw.kw * cw.cin_true,
+                       lambda: lib.xmem_conv2d_nhwc(C.byref(d), ptr(ws), need, stream_ptr()),
+                       (x, out, res, cw, ws, dict(relu_in=bool(relu_in), relu_out=bool(relu_out), in_ld=ldin, cin=cin_h, out_ld=out_ld,
+                                                  res_broadcast=bool(res_broadcast), plan=tuple(plan),
+                                                  executed_mfma_flops=conv_executed_mfma_flops(B, Ho, Wo, cin_h, cw.cout, cw.kh, cw.kw, cw.stride,
+                                                                                               cw.pad, plan[0] if plan[0] <= 6 else 0, False)))))
+    return out
+
+
+def dump_tuned_plans_half(path):
+    allp = dict(_plans_h or _read_plan_file(_PLAN_FILE_H))
+    allp.update(_tuned_now_h)
+    with open(path, 'w') as f:
+        json.dump({k: list(v) for k, v in sorted(allp.items())}, f, indent=0)
+    return len(allp)
+
+
 def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False, in_ld=None, cin=None, plan=None,
-           res_broadcast=False):
+           res_broadcast=False, out_dtype=None):
     """x [B,H,W,C] NHWC (or any buffer whose pixel stride is `in_ld`) -> out [B,Ho,Wo,Cout]."""
     lib = load()
-    _req(x, 'conv2d input')
+    _req(x, 'conv2d input', half_ok=True)
+    if x.dtype == torch.float16:
+        return _conv2d_half(lib, x, cw, out, out_ld, res, relu_in, relu_out, in_ld, cin, plan, res_broadcast, out_dtype)
+    if out_dtype is not None and out_dtype != torch.float32:
+        raise RuntimeError('conv2d: a float32 input gives a float32 output (the fp16 loop converts at the max-pool after the stems)')
     B, H, W = x.shape[0], x.shape[1], x.shape[2]
     ldin = in_ld if in_ld is not None else x.shape[3]
     cin = cin if cin is not None else cw.cin
@@ -467,7 +577,7 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
     explicit = plan is not None                  # a caller-given plan is taken literally (tests, the tuner)
     d.w_winograd = cw.wu.data_ptr() if cw.wu is not None else None
     d.w_winograd_f16 = None
-    if _PRECISION == 'fp16' and cw.wu_f16 is not None and plan is None and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0):
+    if _PRECISION == 'fp16w' and cw.wu_f16 is not None and plan is None and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0):
         d.w_winograd_f16 = cw.wu_f16.data_ptr()
         plan = (16, 1)                       # the library falls back to the fp32 Winograd tile if its own conditions fail
     key = f'{B}x{H}x{W}x{cin}/{ldin}->{cw.cout}/{out_ld} k{cw.kh}s{cw.stride}p{cw.pad} r{int(res is not None)}{int(relu_in)}{int(relu_out)}'
@@ -568,17 +678,21 @@ def trace_marker(tag=0):
     check(load().xmem_trace_marker(int(tag), stream_ptr()))
 
 
-def maxpool3x3s2(x):
+# The elementwise wrappers take float32 or (the fp16 loop) float16 activations: the `_t` entry points carry the storage type of
+# every tensor; outputs follow the input's type unless `out_dtype` says otherwise.
+def maxpool3x3s2(x, out_dtype=None):
     B, H, W, Cc = x.shape
-    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
-    check(load().xmem_maxpool3x3s2(ptr(x), ptr(out), B, H, W, Cc, stream_ptr()))
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    check(load().xmem_maxpool3x3s2_t(ptr(x), _h(x), ptr(out), _h(out), B, H, W, Cc, stream_ptr()))
     return out
 
 
 def upsample2x_add(g, skip):
     B, h, w, Cc = g.shape
-    out = torch.empty((B, 2 * h, 2 * w, Cc), dtype=torch.float32, device=g.device)
-    check(load().xmem_upsample2x_add(ptr(g), ptr(skip), ptr(out), B, h, w, Cc, stream_ptr()))
+    if skip.dtype != g.dtype:
+        raise RuntimeError('upsample2x_add: g and skip must share a storage type')
+    out = torch.empty((B, 2 * h, 2 * w, Cc), dtype=g.dtype, device=g.device)
+    check(load().xmem_upsample2x_add_t(ptr(g), ptr(skip), ptr(out), _h(g), B, h, w, Cc, stream_ptr()))
     return out
 
 
@@ -587,40 +701,42 @@ def area_downsample(x, r, out=None, out_ld=None, out_off=0, c=None, in_ld=None):
     c = c if c is not None else x.shape[3]
     in_ld = in_ld if in_ld is not None else x.shape[3]
     if out is None:
-        out = torch.empty((B, H // r, W // r, c), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, H // r, W // r, c), dtype=x.dtype, device=x.device)
         out_ld = c
-    check(load().xmem_area_downsample(ptr(x), in_ld, C.c_void_p(out.data_ptr() + 4 * out_off), out_ld, B, H, W, c, r, stream_ptr()))
+    check(load().xmem_area_downsample_t(ptr(x), _h(x), in_ld, C.c_void_p(out.data_ptr() + out.element_size() * out_off), _h(out), out_ld,
+                                        B, H, W, c, r, stream_ptr()))
     return out
 
 
 def copy_channels(src, dst, dst_off, c=None, src_off=0):
-    """dst[b, p, dst_off:dst_off+c] = src[b % srcB, p, src_off:src_off+c]; src/dst are [B,H,W,C] buffers."""
+    """dst[b, p, dst_off:dst_off+c] = src[b % srcB, p, src_off:src_off+c]; src/dst are [B,H,W,C] buffers (float32 or float16 each:
+    the copy converts)."""
     B = dst.shape[0]
     P = dst.shape[1] * dst.shape[2]
     c = c if c is not None else src.shape[3]
-    check(load().xmem_copy_channels(C.c_void_p(src.data_ptr() + 4 * src_off), src.shape[3], src.shape[0],
-                                    C.c_void_p(dst.data_ptr() + 4 * dst_off), dst.shape[3], B, P, c, stream_ptr()))
+    check(load().xmem_copy_channels_t(C.c_void_p(src.data_ptr() + src.element_size() * src_off), _h(src), src.shape[3], src.shape[0],
+                                      C.c_void_p(dst.data_ptr() + dst.element_size() * dst_off), _h(dst), dst.shape[3], B, P, c, stream_ptr()))
     return dst
 
 
 def cbam_residual(g, p):
-    """out = g + CBAM(g); p = dict(w1,b1,w2,b2,sw,sb) device tensors."""
+    """out = g + CBAM(g); p = dict(w1,b1,w2,b2,sw,sb) device tensors (float32); g float32 or float16."""
     lib = load()
     B, H, W, Cc = g.shape
     out = torch.empty_like(g)
     need = lib.xmem_cbam_workspace_bytes(B, H * W, Cc)
     ws = workspace(need, g.device, 'cbam')
-    check(lib.xmem_cbam_residual(ptr(g), ptr(out), B, H, W, Cc, ptr(p['w1']), ptr(p['b1']), ptr(p['w2']), ptr(p['b2']),
-                                 ptr(p['sw']), ptr(p['sb']), ptr(ws), need, stream_ptr()))
+    check(lib.xmem_cbam_residual_t(ptr(g), ptr(out), _h(g), B, H, W, Cc, ptr(p['w1']), ptr(p['b1']), ptr(p['w2']), ptr(p['b2']),
+                                   ptr(p['sw']), ptr(p['sb']), ptr(ws), need, stream_ptr()))
     return out
 
 
 def gru_gate(values, h, out=None):
-    """out may be h itself (in-place update of the hidden state)."""
+    """out may be h itself (in-place update of the hidden state).  The state is float32; `values` float32 or float16."""
     B, H, W, Ch = h.shape
     if out is None:
         out = torch.empty_like(h)
-    check(load().xmem_gru_gate(ptr(values), ptr(h), ptr(out), B, H * W, Ch, stream_ptr()))
+    check(load().xmem_gru_gate_t(ptr(values), _h(values), ptr(h), ptr(out), B, H * W, Ch, stream_ptr()))
     return out
 
 
@@ -827,8 +943,8 @@ def readout_sparse(value_segments, w, idx, cv, out, out_ld, obj_stride, out_off=
             arr[o * n_seg + s].n = v.shape[0] if v is not None else 0
     HW, k = w.shape
     e0 = _tap_begin()
-    check(load().xmem_readout_sparse(arr, n_obj, n_seg, ptr(w), ptr(idx), HW, k, cv,
-                                     C.c_void_p(out.data_ptr() + 4 * out_off), out_ld, obj_stride, stream_ptr()))
+    check(load().xmem_readout_sparse_t(arr, n_obj, n_seg, ptr(w), ptr(idx), HW, k, cv,
+                                       C.c_void_p(out.data_ptr() + out.element_size() * out_off), _h(out), out_ld, obj_stride, stream_ptr()))
     _tap_end('readout', e0, 2.0 * cv * k * HW * n_obj)
 
 
