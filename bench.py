@@ -539,6 +539,7 @@ def run_cpu_baseline(res, args, device):
     gpu.cancel_prefetch()
     del dev
     ious, mism, perr = [], 0, 0.0
+    cpu_masks = []
     pos = [0]
 
     def cpu_frames(n):
@@ -550,6 +551,7 @@ def run_cpu_baseline(res, args, device):
             m = R.post_process(p)
             ts.append(time.perf_counter() - t0)
             g, pg = gpu_out[i]
+            cpu_masks.append(np.asarray(m))
             ious.append(R.compute_array_iou(g, m))
             nonlocal mism, perr
             mism += int((g != m).sum())
@@ -565,6 +567,27 @@ def run_cpu_baseline(res, args, device):
     torch.set_num_threads(best_t)
     cpu_frames(3)
     ts = cpu_frames(args.cpu_frames)
+    floor = None
+    if wl['K'] > 1:
+        # multi-object streams: the reference path's OWN thread-count noise on exactly these frames next
+        # to the GPU figures - the same oracle again at 1 thread (the goldens' count) vs the run above (thread sweep, then best_t)
+        torch.set_num_threads(1)
+        ref1 = R.RefCore(R.RefNet(res['sd']), cfg)
+        ref1.set_all_labels(list(range(1, wl['K'] + 1)))
+        for j in range(wl['perm']):
+            ref1.put_to_permanent_memory(torch.from_numpy(fr[j]), torch.from_numpy(mk[j]))
+        one = [np.asarray(R.post_process(ref1.step(cpu_frame(i), None, None))) for i in range(len(cpu_masks))]
+
+        def clip_stats(a, b):
+            A, B = np.stack(a), np.stack(b)
+            return dict(iou_per_object=[float(((A == c) & (B == c)).sum() / max(((A == c) | (B == c)).sum(), 1)) for c in range(1, wl['K'] + 1)],
+                        argmax_mismatch_pixels=int((A != B).sum()), pixels=int(A.size))
+        floor = dict(frames=len(one),
+                     oracle_sweep_threads_vs_oracle_1_thread=clip_stats(cpu_masks, one),
+                     gpu_vs_oracle_1_thread=clip_stats([g for g, _ in gpu_out[:len(one)]], one),
+                     gpu_vs_oracle_sweep_threads=clip_stats([g for g, _ in gpu_out[:len(one)]], cpu_masks),
+                     note='clip-level IoU per object and argmax mismatch over the same frames; the reference path at two thread counts '
+                          'differs from itself by the first entry (tests/test_gpu_e2e.py gates the GPU path against 1.5x that floor)')
     torch.set_num_threads(all_threads)
     fps = 1.0 / float(np.median(ts))
     return dict(value=fps, unit='frames/s', cores=best_t, kind='port',
@@ -574,7 +597,8 @@ def run_cpu_baseline(res, args, device):
                        f'(1 warm-up + 3 timed frames each), then 3 warm-up + {len(ts)} timed frames of step()+argmax at the '
                        f'best count ({best_t} threads); oracle/cpu_ref.py; host has {os.cpu_count()} logical CPUs'), \
         dict(mask_iou_vs_cpu_min=float(min(ious)), mask_iou_vs_cpu_mean=float(np.mean(ious)), argmax_mismatch_pixels=mism,
-             frames_compared=len(ious), pixels_per_frame=wl['H'] * wl['W'], max_abs_prob_err_ds8=perr)
+             frames_compared=len(ious), pixels_per_frame=wl['H'] * wl['W'], max_abs_prob_err_ds8=perr,
+             **({'oracle_thread_noise_floor': floor} if floor is not None else {}))
 
 
 def run_sampled_readout_check(res, device, n_pick=32):

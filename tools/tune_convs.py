@@ -32,11 +32,17 @@ for (H, W, K) in [(480, 854, 1), (480, 854, 2), (480, 854, 3), (720, 1280, 1), (
     # the decoder fuser with its frame-only half pre-convolved in the key pass (prefetched frames): the per-object half's shapes
     h16, w16 = (H + 15) // 16, (W + 15) // 16
     with ops.precision(PREC):
-        xf = torch.randn(1, h16, w16, 1024, device='cuda')
+        xf = torch.randn(1, h16, w16, 1024, device='cuda').to(ops.act_dtype())
         pre = (ops.conv2d(xf, net._w['decoder.fuser.block1.conv1@x'], relu_in=True), ops.conv2d(xf, net._w['decoder.fuser.block1.downsample@x']))
-        net._fusion(torch.randn(K, h16, w16, 1024 + 512 + 64, device='cuda'), 'decoder.fuser', x=xf, pre=pre)
+        net._fusion(torch.randn(K, h16, w16, 1024 + 512 + 64, device='cuda').to(ops.act_dtype()), 'decoder.fuser', x=xf, pre=pre)
     torch.cuda.synchronize()
     print(H, W, K, 'plans so far', len(ops._tuned_now_x if PREC == 'fp32x' else ops._tuned_now))
+if PREC == 'fp16':                           # the fp16 loop's half kernels: their own table (conv_plans_fp16.json)
+    n = ops.dump_tuned_plans_half(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/conv_plans_fp16.json')
+    print('dumped', n)
+    for k, v in sorted(ops._tuned_now_h.items()):
+        print(k, v)
+    sys.exit(0)
 n = ops.dump_tuned_plans(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/conv_plans.json', split=(PREC == 'fp32x'))
 print('dumped', n)
 for k, v in sorted((ops._tuned_now_x if PREC == 'fp32x' else ops._tuned_now).items()):
