@@ -50,6 +50,10 @@ HALF_CONV_CASES = [
     (1, 60, 108, 256, 256, 3, 1, True, True, True, False, (1, 1)),       # 128x128 tile
     (3, 15, 27, 576, 192, 3, 1, False, False, False, False, (2, 1)),     # 128x64 tile, ragged rows
     (1, 17, 23, 64, 96, 3, 1, False, False, False, False, (3, 1)),       # ragged M and N tails
+    (1, 60, 108, 256, 256, 3, 1, True, True, True, False, (4, 1)),       # 256x128 tile, 8 waves
+    (2, 30, 54, 512, 192, 1, 1, False, True, True, False, (4, 1)),       # 256x128, pointwise loader, masked column block
+    (1, 30, 54, 576, 512, 3, 1, False, False, False, False, (4, 2)),     # 256x128 + split-K
+    (1, 30, 54, 1024, 129, 3, 1, False, False, False, True, (4, 1)),     # 256x128, fp32 output
 ]
 
 

@@ -69,14 +69,14 @@ __device__ __forceinline__ f32x4 split_pack(const f32x4 v) {
 // projection, split-K partials) or rounded once to fp16 (HALF = 2: every activation).  Eight halfs occupy the 16 bytes of four
 // floats, so with Cin, ldin and K passed in 4-byte units (Cin / 2, ...) every loader of this file is unchanged; a 16-byte
 // fragment is ONE fp16 MFMA (k = 16: 8 halfs per lane half) instead of four fp32 ones.
-template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false, bool SPLIT = false, int HALF = 0>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
+template <int BM, int BN, int TM, int TN, int BK, bool GENERIC, bool ONE = false, bool SPLIT = false, int HALF = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
     constexpr int WN = BN / (32 * TN);
     constexpr int WM = BM / (32 * TM);
-    static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(WM * WN == NW, "NW waves per workgroup (4; 8 for the 256x128 tile of the fp16 loop)");
     constexpr int LDK = BK + 4;
     constexpr int C4 = BK / 4;                 // float4 columns per staged row
-    constexpr int RPP = 256 / C4;              // rows staged per pass of the 256 threads
+    constexpr int RPP = 64 * NW / C4;          // rows staged per pass of the workgroup's threads
     constexpr int RA = BM / RPP, RB = BN / RPP;
     constexpr int BUF = (BM + BN) * LDK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1072,8 +1072,24 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = fa
     return xmem_check_launch();
 }
 
+// fp16 loop only: 256x128 tile, 8 waves (4 x 2, each 64x64 = four accumulators): 1/85 byte of operand traffic per FLOP instead of
+// 1/64 - the half kernels are bound by the L2 -> LDS operand stream, not by the matrix pipe
+template <bool G>
+int launch_half_256(const ConvArgs& a, hipStream_t s, int half) {
+    const size_t lds = 2 * (size_t)(256 + 128) * 36 * sizeof(float);
+    const bool one = !G && conv_is_one(a);
+    auto kern = conv_mfma_kernel<256, 128, 2, 2, 32, G, false, false, 2, 8>;
+    if (half == 2) { if (one) kern = conv_mfma_kernel<256, 128, 2, 2, 32, false, true, false, 2, 8>; }
+    else kern = one ? conv_mfma_kernel<256, 128, 2, 2, 32, false, true, false, 1, 8> : conv_mfma_kernel<256, 128, 2, 2, 32, G, false, false, 1, 8>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+    return xmem_check_launch();
+}
+
 template <int BK, bool G>
 int launch_bk(const Plan& pl, const ConvArgs& a, hipStream_t s, int groups = 1) {
+    if (pl.bm == 256) return launch_half_256<G>(a, s, pl.half);
     if (pl.bm == 128 && pl.bn == 128) return launch_cfg<128, 128, 2, 2, BK, G>(a, s, groups, pl.split, pl.half);
     if (pl.bm == 128 && pl.bn == 64) return launch_cfg<128, 64, 2, 1, BK, G>(a, s, groups, pl.split, pl.half);
     return launch_cfg<64, 64, 1, 1, BK, G>(a, s, groups, pl.split, pl.half);
@@ -1087,8 +1103,18 @@ static bool half_view(const xmem_conv_desc* d, xmem_conv_desc& v) {
     v = *d;
     v.Cin = d->Cin / 2; v.ldin = d->ldin / 2;
     v.w_winograd = nullptr; v.w_winograd4 = nullptr; v.w_winograd_f16 = nullptr; v.arith = 0; v.w_split = nullptr;
-    if (v.plan_tile > 3) v.plan_tile = (v.plan_tile <= 6) ? v.plan_tile - 3 : 0;      // BK = 32 (64 halfs) tiles only
+    if (v.plan_tile == 4) v.plan_tile = 104;                                          // 256x128 (8 waves), resolved by the caller
+    else if (v.plan_tile > 3) v.plan_tile = (v.plan_tile <= 6) ? v.plan_tile - 3 : 0;  // BK = 32 (64 halfs) tiles only
     return true;
+}
+
+// plan of a half-typed call: plan_tile 1..3 = {128x128, 128x64, 64x64}, 4 = 256x128 (8 waves), 0 = heuristic
+static Plan make_plan_half(xmem_conv_desc& v) {
+    const bool big = v.plan_tile == 104;
+    if (big) v.plan_tile = 1;
+    Plan pl = make_plan(&v);
+    if (big && pl.bm != 0) { pl.bm = 256; pl.bn = 128; }
+    return pl;
 }
 
 extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
@@ -1098,7 +1124,7 @@ extern "C" size_t xmem_conv2d_workspace_bytes(const xmem_conv_desc* d) {
         if (!half_view(d, hv)) return 0;
         d = &hv;
     }
-    Plan pl = make_plan(d);
+    Plan pl = d->in_half ? make_plan_half(hv) : make_plan(d);
     int Ho, Wo; out_dims(d, Ho, Wo);
     if (pl.wino && pl.wino4) return (size_t)36 * d->B * cdiv(Ho, 4) * cdiv(Wo, 4) * (d->Cin + d->Cout) * sizeof(float);
     if (pl.wino && pl.f16) return align_up((size_t)16 * d->B * cdiv(Ho, 2) * cdiv(Wo, 2) * d->Cin * 2, 256) +
@@ -1119,7 +1145,7 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         if (!half_view(d, hv)) return XMEM_ERR_UNSUPPORTED;
         d = &hv;
     } else if (d->out_half) return XMEM_ERR_UNSUPPORTED;                    // half output needs half input (the stems stay fp32)
-    Plan pl = make_plan(d);
+    Plan pl = half ? make_plan_half(hv) : make_plan(d);
     pl.half = half;
     int Ho, Wo; out_dims(d, Ho, Wo);
     ConvArgs a;

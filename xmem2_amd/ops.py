@@ -508,7 +508,7 @@ def _conv2d_half(lib, x, cw, out, out_ld, res, relu_in, relu_out, in_ld, cin, pl
             plan = (0, 0)
             if AUTOTUNE and cw.cout > 1 and not torch.cuda.is_current_stream_capturing():
                 best, best_t = (0, 0), None
-                for tile in (1, 2, 3):
+                for tile in (1, 2, 3, 4):                 # 4 = 256x128, 8 waves (half kernels only)
                     for sk in (1, 2, 4, 8):
                         t = _time_plan(lib, d, x.device, (tile, sk), reps=8)
                         if t is not None and (best_t is None or t < best_t):
@@ -525,7 +525,7 @@ def _conv2d_half(lib, x, cw, out, out_ld, res, relu_in, relu_out, in_ld, cin, pl
                        (x, out, res, cw, ws, dict(relu_in=bool(relu_in), relu_out=bool(relu_out), in_ld=ldin, cin=cin_h, out_ld=out_ld,
                                                   res_broadcast=bool(res_broadcast), plan=tuple(plan),
                                                   executed_mfma_flops=conv_executed_mfma_flops(B, Ho, Wo, cin_h, cw.cout, cw.kh, cw.kw, cw.stride,
-                                                                                               cw.pad, plan[0] if plan[0] <= 6 else 0, False)))))
+                                                                                               cw.pad, {4: 1}.get(plan[0], plan[0]) if plan[0] <= 6 else 0, False)))))
     return out
 
 
