@@ -538,7 +538,7 @@ def run_cpu_baseline(res, args, device):
         gpu_out.append((ops.argmax_u8(pg).cpu().numpy(), pg[:, 4::8, 4::8].cpu()))
     gpu.cancel_prefetch()
     del dev
-    ious, mism, perr = [], 0, 0.0
+    ious, mism, perr, clear_mism, near_tie = [], 0, 0.0, 0, 0
     cpu_masks = []
     pos = [0]
 
@@ -553,9 +553,13 @@ def run_cpu_baseline(res, args, device):
             g, pg = gpu_out[i]
             cpu_masks.append(np.asarray(m))
             ious.append(R.compute_array_iou(g, m))
-            nonlocal mism, perr
+            nonlocal mism, perr, clear_mism, near_tie
             mism += int((g != m).sum())
             perr = max(perr, float((pg - p[:, 4::8, 4::8]).abs().max()))
+            top2 = torch.topk(p, 2, dim=0).values                       # the CPU path's own top-2 margin per pixel
+            margin = (top2[0] - top2[1]).numpy()
+            clear_mism += int(((g != np.asarray(m)) & (margin > 5e-2)).sum())
+            near_tie += int((margin < 1e-2).sum())
         return ts
 
     sweep_fps = {}
@@ -598,6 +602,8 @@ def run_cpu_baseline(res, args, device):
                        f'best count ({best_t} threads); oracle/cpu_ref.py; host has {os.cpu_count()} logical CPUs'), \
         dict(mask_iou_vs_cpu_min=float(min(ious)), mask_iou_vs_cpu_mean=float(np.mean(ious)), argmax_mismatch_pixels=mism,
              frames_compared=len(ious), pixels_per_frame=wl['H'] * wl['W'], max_abs_prob_err_ds8=perr,
+             argmax_mismatch_pixels_at_clear_cpu_margin=clear_mism, clear_margin=5e-2,
+             cpu_pixels_near_tie_fraction=near_tie / max(len(ious) * wl['H'] * wl['W'], 1), near_tie_margin=1e-2,
              **({'oracle_thread_noise_floor': floor} if floor is not None else {}))
 
 

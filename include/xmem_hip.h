@@ -38,7 +38,10 @@ typedef enum {
     XMEM_ERR_TOPK = -5          /* fewer memory elements than top_k (torch.topk raises, memory_util.py:46) */
 } xmem_status;
 
-int xmem_version(void);                       /* ABI version, currently 1 */
+/* ABI version of this header.  2 (round 4): xmem_conv_desc grew (in_half / out_half / w_half), storage-typed `_t` entry points, plan
+ * tiles 23..40.  A caller compiled against another version must not pass structs: check xmem_version() == XMEM_ABI_VERSION at load. */
+#define XMEM_ABI_VERSION 2
+int xmem_version(void);
 const char* xmem_last_error_string(int code); /* static string for a status code */
 
 /* Measurement aid: launches the empty kernel `xmem_trace_marker_kernel` on `stream`.  A rocprofv3 kernel trace of a

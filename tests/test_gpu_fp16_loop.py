@@ -170,13 +170,16 @@ def test_fp16_loop_end_to_end_vs_fp32_goldens(synth_sd, tag, hw, n_obj, min_iou,
         core.put_to_permanent_memory(frames[int(j)], masks[int(j)])
     assert core.memory.permanent_work_mem.value_rows(0).dtype == torch.float32
     mask_frames = set(int(x) for x in g['mask_frames'])
-    out, sizes, perr = [], [], 0.0
+    out, sizes, perr, clear_diff = [], [], 0.0, 0
     for ti in range(t):
         mk = masks[ti] if ti in mask_frames else None
         p = core.step(frames[ti], mk, labels if mk is not None else None, end=(ti == t - 1), do_not_add_mask_to_memory=(mk is not None))
         assert p.dtype == torch.float32 and p.shape == (n_obj + 1,) + tuple(hw) and bool(torch.isfinite(p).all())
         out.append(ops.argmax_u8(p).cpu().numpy())
-        perr = max(perr, float(np.abs(p[:, 4::8, 4::8].cpu().numpy() - g['prob_ds8'][ti]).mean()))
+        ps, pr = p[:, 4::8, 4::8].cpu().numpy(), g['prob_ds8'][ti]
+        perr = max(perr, float(np.abs(ps - pr).mean()))
+        srt = np.sort(pr, axis=0)
+        clear_diff += int(((ps.argmax(0) != pr.argmax(0)) & ((srt[-1] - srt[-2]) > 5e-2)).sum())     # sampled grid of the goldens
         m = core.memory
         sizes.append([m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size])
     got, ref = np.stack(out), g['argmax']
@@ -186,6 +189,9 @@ def test_fp16_loop_end_to_end_vs_fp32_goldens(synth_sd, tag, hw, n_obj, min_iou,
     mism = float((got != ref).mean())
     print(f'fp16 loop, {tag}: clip IoU per object {[round(float(v), 5) for v in iou]}, argmax mismatch {mism:.2e}, worst mean |dp| {perr:.2e}')
     assert all(v >= m for v, m in zip(iou, min_iou)) and mism < max_mism and perr < 5e-3
+    # what the mode guarantees: probabilities within fp16 noise, hence the same argmax wherever the reference's own top-2 margin is
+    # clear (the differences above are near-ties: profiles/r04_fp16_loop_margins.txt)
+    assert clear_diff == 0, f'{clear_diff} sampled pixels differ in argmax where the reference margin exceeds 5e-2'
 
 
 def test_fp16_loop_stage_outputs_vs_fp32(synth_sd):

@@ -86,7 +86,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/xmem_hip.h but not exported'
     assert set(declared) == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.xmem_version() == 1
+    assert lib.xmem_version() == 2
     assert b'top_k' in lib.xmem_last_error_string(-5)
 
 

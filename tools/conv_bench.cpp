@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
     static const double G2[12] = {1, 0, 0, 0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 0, 0, 1};
     static const double G4[18] = {0.25, 0, 0, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6,
                                   1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 24, -1.0 / 12, 1.0 / 6, 0, 0, 1};
+    if (xmem_version() != XMEM_ABI_VERSION) { fprintf(stderr, "libxmem_hip.so has ABI version %d, this driver was built for %d: rebuild tools/conv_bench\n", xmem_version(), XMEM_ABI_VERSION); return 2; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& job : jobs) {

@@ -30,6 +30,8 @@ static Lib open_lib(const std::string& path, const char* tag) {
     if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", path.c_str(), dlerror()); exit(2); }
     l.conv = (conv_fn)dlsym(l.h, "xmem_conv2d_nhwc"); l.convws = (convws_fn)dlsym(l.h, "xmem_conv2d_workspace_bytes");
     l.up = (up_fn)dlsym(l.h, "xmem_upsample2x_add");
+    int (*ver)(void) = (int (*)(void))dlsym(l.h, "xmem_version");
+    if (!ver || ver() != XMEM_ABI_VERSION) { fprintf(stderr, "%s: ABI version mismatch (rebuild: bash tools/probes/pk_hazard/build.sh lib)\n", path.c_str()); exit(2); }
     if (!l.conv || !l.convws || !l.up) { fprintf(stderr, "missing symbols in %s\n", path.c_str()); exit(2); }
     return l;
 }

@@ -16,6 +16,9 @@ c_float_p = C.c_void_p
 c_void_p = C.c_void_p
 
 
+ABI_VERSION = 2          # include/xmem_hip.h XMEM_ABI_VERSION: the layout of ConvDesc below belongs to it
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('inp', C.c_void_p), ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('ldin', C.c_int),
                 ('w', C.c_void_p), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
@@ -133,7 +136,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.xmem_version() != 1:
+    if lib.xmem_version() != ABI_VERSION:
         raise XMemHipError('libxmem_hip.so ABI version mismatch')
     _lib = lib
     return lib

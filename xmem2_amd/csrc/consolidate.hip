@@ -4,7 +4,7 @@
 #include "common.hpp"
 #include <math.h>
 
-extern "C" int xmem_version(void) { return 1; }
+extern "C" int xmem_version(void) { return XMEM_ABI_VERSION; }
 
 __global__ void xmem_trace_marker_kernel(int tag) { (void)tag; }
 extern "C" int xmem_trace_marker(int tag, void* stream) {
