@@ -256,7 +256,8 @@ class InferenceCore:
             value, hidden = net.encode_value_nhwc(image4, f16, mem.get_hidden(), prob_padded[1:],
                                                   is_deep_update=is_deep_update, slot=slot)
             if value.dtype != torch.float32:          # fp16 loop: the memory keeps fp32 values (as torch.cat promotes the reference's
-                value = value.float()                 # fp16 values onto its fp32-preloaded stores, kv_memory_store.py:36-94)
+                v32 = torch.empty(value.shape, dtype=torch.float32, device=value.device)   # fp16 values onto its fp32-preloaded
+                value = ops.copy_channels(value, v32, 0)                                     # stores, kv_memory_store.py:36-94)
             mem.add_memory(key, shrinkage, value.view(value.shape[0], h * w, value.shape[3]), self.all_labels,
                            selection=selection if self.enable_long_term else None, ignore=is_ignore, hw_shape=(h, w))
             self.last_mem_ti = self.curr_ti
