@@ -115,20 +115,29 @@ __global__ __launch_bounds__(256) void affinity_rows16_kernel(const float* __res
 //            consecutive 288-byte rows - whole cache lines, 9 pieces per thread and stage, one address add per piece on the
 //            regular stage (one segment, no clamped row); double buffered, one barrier per stage; every wave reads every
 //            tile's fragments from LDS (ds_read_b128, row stride 304 B: conflict-free), two k-steps ahead of their MFMAs
-//   per wave and PAIR of tiles: 9 k-steps x (2 row fragments from LDS, 4 MFMAs: 2 tiles x 2 query blocks), then 16 compares
-//            per lane and (tile, query block) against tau, collected in the lane's own halfword of the bit matrix.
-// Round 2 kept 128 queries in LDS and loaded the rows as MFMA fragments straight from global memory (one lane per row:
-// 32 cache lines per load instruction, every row crossing L2 -> CU once per 128 queries): 972 us at 921 600 x 3 600,
-// 9.56 ms at 4 177 920 x 8 160.  This layout: 864 us / 8.15 ms (8 waves), 37 us (was 40) at 51 840 x 1 620.  Counters at
-// 921 600 x 3 600: matrix pipe busy 0.47 of the kernel's cycles at 2.2 GHz, VALU busy about the same, a third of the wave
-// cycles waiting - the two waves of a SIMD cover only part of each other's address / compare / barrier phases.
+//   compares software-pipelined inside the wave: two accumulator sets of one tile x 2 query blocks; behind each of the 18 MFMAs
+//            of tile j + 1 (32 cycles each in the pipe) two compares of tile j against tau - accumulator array a under MFMAs
+//            1 + 8a .. 8 + 8a, then its 64 halfwords of the bit matrix are stored.  A compare (v_cmp_nlt: NaN-safe "upper
+//            estimate >= tau", true for a non-finite estimate - the exact pass decides) writes its lane mask to an SGPR pair
+//            of its own; the add-with-carry that shifts the bit into the lane's halfword runs one MFMA slot later (r = 0 ends
+//            up in bit 15).  The results of a tile's last MFMA are first read after three later MFMAs have been issued behind
+//            it (in-order pipe): that covers the MFMA -> VALU read hazard the compiler cannot see through asm statements.
+// Everything stays in 228 VGPRs, two waves per SIMD (a v_accvgpr_read beside MFMAs costs 8 cycles, a lone wave hides at most
+// ~5 single-issue instructions per MFMA: tools/probes/mfma_shadow).  Round 3 ran each pair of tiles' 36 MFMAs and then its 64
+// compares as a block, leaving the overlap to the two waves of a SIMD: 35.9 us / 884 us / 8.26 ms at the three served sizes
+// (51 840 x 1 620, 921 600 x 3 600, 4 177 920 x 8 160); this schedule: 33.5 us / 823 us / 7.91 ms = 0.30 / 0.48 / 0.50 of the
+// nominal fp16 peak.  The bound is the chip's power budget, not the schedule: a register-only loop of the same MFMA on random
+// operands sustains 0.60 - 0.66 of the nominal peak (0.90 - 0.95 on zeros; tools/probes/mfma_shadow/mfma_sustained.hip), and
+// this kernel with its row fetch, LDS hand-over and bit stores knocked out runs at 0.61 - 0.63
+// (profiles/r04_filter_kernel_ab.txt).  (Round 2 kept 128 queries in LDS and loaded the rows as MFMA fragments straight from
+// global memory: 972 us / 9.56 ms.)
 // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 (round-robin dispatch); all query tiles of one split - the workgroups
 // that stream the SAME rows - share L % 8 and neighbouring slots.
 // PASS2 = the second pass over the flagged 128-query tiles (its own kernel name: a trace tells the working launch from the one
-// that normally returns at once)
-template <bool PASS2, int NW>
+// that normally returns at once).  DBG: knock-outs for tools builds (-DXMEM_TOOLS), 0 in the shipped instantiations.
+template <bool PASS2, int NW, int DBG = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity_filter16_kernel(Filter16Args p) {
-    constexpr int F16_STAGE = NW, F16_WGQ = 64 * NW, NTHR = 64 * NW;
+    constexpr int NQB = 2, F16_STAGE = NW, F16_WGQ = 64 * NW, NTHR = 64 * NW;
     __shared__ __attribute__((aligned(16))) unsigned char Ah[2][F16_STAGE * AFF_ROWS * F16_LDB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
     const int qtile = slot % p.qtiles;
     const int split = (blockIdx.x & 7) + 8 * (slot / p.qtiles);
     if (split >= p.splits) return;
-    const int b0 = qtile * (F16_WGQ / 32) + wave * 2;            // this wave's first query block
+    const int b0 = qtile * (F16_WGQ / 32) + wave * NQB;          // this wave's first query block
     bool active = b0 * 32 < p.HW;                                // (wave-uniform)
     if (PASS2) {                                                 // pass 2: flagged 128-query tiles only
         const int nflag = (p.HW + F16_BQ - 1) / F16_BQ, f = (F16_WGQ / F16_BQ) * qtile;
@@ -145,13 +154,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
 #pragma unroll
         for (int i = 0; i < F16_WGQ / F16_BQ; ++i) any = any || (f + i < nflag && p.only[f + i] != 0);
         if (!any) return;
-        if (active) active = p.only[b0 >> 2] != 0;
+        if (active) active = p.only[b0 >> 2] != 0;               // (a wave's two blocks lie in one flag tile)
     }
 
-    h16x8 bq[2][9];
-    float my_tau[2];
+    h16x8 bq[NQB][9];
+    float my_tau[NQB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NQB; ++i) {
         const int q = (b0 + i) * 32 + l31;
         const bool ok = active && q < p.HW;
         const _Float16* src = p.qop16 + (size_t)min(q, p.HW - 1) * F16_K + lh * 8;
@@ -164,18 +173,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
             }
             bq[i][t] = v;
         }
-        // a query without a bound (-inf) keeps every pair: its list fills up, flags the tile, and the tighten pass makes a bound
-        my_tau[i] = ok ? p.tau[q] : INFINITY;
+        my_tau[i] = ok ? p.tau[q] : INFINITY;                    // (no bound: -inf keeps every pair, see the kernel above)
     }
 
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
     const int nst = (t_end - t_begin + F16_STAGE - 1) / F16_STAGE;
 
-    // one stage = F16_STAGE tiles x 32 rows x 18 pieces of 16 bytes = 9 pieces per thread.  Row index clamped into the segment
-    // (the duplicated rows of a segment's last tile set spurious bits; the scan drops rows past the segment's end)
-    // (the segment table is copied to scalars once: read from the kernel arguments inside the loop it cost a scalar load and a
-    // wait per piece; tiles past the split's end repeat its last tile - branch-free loads, nobody reads those slots)
+    // stage fetch: as in the kernel above (9 pieces of 16 bytes per thread; FAST stage = one contiguous range)
     static_assert(XMEM_MAX_SEGMENTS == 4, "segment select below is written out for 4 segments");
     const int gt1 = 1 < p.n_seg ? p.seg[1].tile0 : 0x7fffffff, gt2 = 2 < p.n_seg ? p.seg[2].tile0 : 0x7fffffff,
               gt3 = 3 < p.n_seg ? p.seg[3].tile0 : 0x7fffffff;
@@ -184,8 +189,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
                    *gr3 = 3 < p.n_seg ? p.seg[3].rows16 : gr0;
     const int gt0 = p.seg[0].tile0;
     uint4 st0, st1, st2, st3, st4, st5, st6, st7, st8;
-    // FAST stage (the rule; decided per stage with scalar arithmetic): its tiles lie in one segment, none is the segment's
-    // clamped last tile and none is past the split - the stage is F16_STAGE x 9216 contiguous bytes, piece e at byte 16 e
     const unsigned char* fbase = nullptr;
     bool ffast = false;
 #define F16_STAGE_SETUP(S)                                                                                           \
@@ -229,86 +232,102 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
         F16_STASH_ONE(5, st5) F16_STASH_ONE(6, st6) F16_STASH_ONE(7, st7) F16_STASH_ONE(8, st8)                      \
     }
 
-    // a pair of tiles of the current stage: 36 MFMAs (four independent accumulator chains), the row fragments of step t + 1
-    // requested from LDS before the MFMAs of step t; then the compares
-    // (Fetching piece t and storing it inside the k-steps of the pairs - address arithmetic and LDS stores under the MFMAs
-    // instead of in blocks of their own - was measured 12 % SLOWER at 921 600 x 3 600: extra issue slots between MFMAs cost
-    // more than the blocks do.)
-    // (the pair body is written into the stage loop - `PAIR BODY` - rather than a lambda: as a lambda with a call site in a
-    // loop its captured variables stayed in scratch memory)
-    int tido = tid;                                   // (made opaque once per stage: the per-piece row / part numbers are
-                                                      // recomputed instead of living in 18 registers across the loop)
+    f32x16 cA[NQB], cB[NQB];                                     // the two accumulator sets: one TILE x NQB query blocks each
+#pragma unroll
+    for (int i = 0; i < NQB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { cA[i][r] = 0.f; cB[i][r] = 0.f; }
+    unsigned bits[NQB];
+#pragma unroll
+    for (int a = 0; a < NQB; ++a) bits[a] = 0u;
+    h16x8 fr[9];
+    unsigned short* const mask16 = reinterpret_cast<unsigned short*>(p.mask);
+    unsigned long long pmk0 = 0ull, pmk1 = 0ull;                 // lane masks of the two compares of the previous MFMA slot
+    unsigned sink = 0u;                                          // (tools: knock-out 8 keeps the compares alive without the stores)
+
+    // one k-step of the CURRENT tile (accumulators CUR, fragments from AR) with the compares of the PENDING tile (PRV, tile number
+    // PT, stored when PTOK) behind its MFMAs; the fragment of step T + F16_PF is requested first - for the last steps of a tile
+    // that is a first fragment of the NEXT tile of the same stage (ARN; the stage's last tile has no successor before the barrier)
+#define F16P_COMPARE(PRV, M, PT, PTOK)                                                                                \
+    if (!(DBG & 2)) {                                                                                                 \
+        /* consume: the two lane masks slot M - 1 produced are shifted into their array's halfword (bit 15 - r <-> r) */   \
+        if ((M) >= 2 && (M) < 2 + 8 * NQB) {                                                                          \
+            const int a_ = ((M) - 2) >> 3, e_ = (((M) - 2) & 7) * 2;                                                  \
+            unsigned long long junk0, junk1;                                                                          \
+            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk0) : "s"(pmk0));                     \
+            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk1) : "s"(pmk1));                     \
+            if ((DBG & 8) && e_ == 14) sink ^= bits[a_];                                                              \
+            else if (e_ == 14 && (PTOK) && (b0 + a_) * 32 < p.HW)                                                     \
+                mask16[(((size_t)(b0 + a_) * p.total_tiles + (PT)) << 6) + lane] = (unsigned short)bits[a_];          \
+        }                                                                                                             \
+        /* produce: two compares of the pending tile into two SGPR pairs of their own (nothing waits for them here) */     \
+        if ((M) >= 1 && (M) < 1 + 8 * NQB) {                                                                          \
+            const int a_ = ((M) - 1) >> 3, e_ = (((M) - 1) & 7) * 2;                                                  \
+            if (e_ == 0) bits[a_] = 0u;                                                                               \
+            asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(pmk0) : "v"(PRV[a_][e_]), "v"(my_tau[a_]));                      \
+            asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(pmk1) : "v"(PRV[a_][e_ + 1]), "v"(my_tau[a_]));                  \
+        }                                                                                                             \
+    }
+#define F16P_KSTEP(T, CUR, PRV, AR, ARN, HASN, PT, PTOK)                                                              \
+    {                                                                                                                 \
+        if ((T) + F16_PF < 9) fr[((T) + F16_PF) % 9] = *reinterpret_cast<const h16x8*>((AR) + ((T) + F16_PF) * 32);   \
+        else if (HASN) fr[((T) + F16_PF) % 9] = *reinterpret_cast<const h16x8*>((ARN) + (((T) + F16_PF) % 9) * 32);   \
+        _Pragma("unroll") for (int i = 0; i < NQB; ++i) {                                                             \
+            if ((T) == 0) {                                                                                           \
+                f32x16 z;                                                                                             \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.f;                                            \
+                CUR[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0], bq[i][0], z, 0, 0, 0);                         \
+            } else {                                                                                                  \
+                CUR[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[T], bq[i][T], CUR[i], 0, 0, 0);                    \
+            }                                                                                                         \
+            F16P_COMPARE(PRV, (T) * NQB + i, PT, PTOK)                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
+    }
+#define F16P_TILE(CUR, PRV, AR, ARN, HASN, PT, PTOK)                                                                  \
+    F16P_KSTEP(0, CUR, PRV, AR, ARN, HASN, PT, PTOK) F16P_KSTEP(1, CUR, PRV, AR, ARN, HASN, PT, PTOK)                 \
+    F16P_KSTEP(2, CUR, PRV, AR, ARN, HASN, PT, PTOK) F16P_KSTEP(3, CUR, PRV, AR, ARN, HASN, PT, PTOK)                 \
+    F16P_KSTEP(4, CUR, PRV, AR, ARN, HASN, PT, PTOK) F16P_KSTEP(5, CUR, PRV, AR, ARN, HASN, PT, PTOK)                 \
+    F16P_KSTEP(6, CUR, PRV, AR, ARN, HASN, PT, PTOK) F16P_KSTEP(7, CUR, PRV, AR, ARN, HASN, PT, PTOK)                 \
+    F16P_KSTEP(8, CUR, PRV, AR, ARN, HASN, PT, PTOK)
+
+    int tido = tid;
     F16_FETCH(0)
     F16_STASH(&Ah[0][0])
     __syncthreads();
     for (int s = 0; s < nst; ++s) {
-        // (the last stage fetches its own tiles again instead of branching around the loads: the staging registers stay
-        // plain registers for the compiler)
         asm volatile("" : "+v"(tido));
-        F16_FETCH(min(s + 1, nst - 1))
+        if (!(DBG & 1)) F16_FETCH(min(s + 1, nst - 1))
         if (active) {
             const int tile = t_begin + s * F16_STAGE;
+            const unsigned char* ar = &Ah[s & 1][0] + l31 * F16_LDB + lh * 16;
+            constexpr int TILEB = AFF_ROWS * F16_LDB;
+            // (tiles past the split's end hold copies of its last tile: their MFMAs run, their bits are not stored)
+#pragma unroll
+            for (int t = 0; t < F16_PF; ++t) fr[t] = *reinterpret_cast<const h16x8*>(ar + t * 32);
 #pragma nounroll
-            for (int g = 0; g < F16_STAGE; g += 2) {
-                const int nt = min(2, t_end - (tile + g));
-                if (nt <= 0) break;
-                const unsigned char* A = &Ah[s & 1][g * AFF_ROWS * F16_LDB];
-                const int tl = tile + g;
-                // ---- PAIR BODY
-                const unsigned char* ar = A + l31 * F16_LDB + lh * 16;
-                f32x16 c[2][2];
-                h16x8 fr[9][2];                                              // (constant indices after unrolling: three steps live)
-#pragma unroll
-                for (int t = 0; t < F16_PF; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) fr[t][u] = *reinterpret_cast<const h16x8*>(ar + u * AFF_ROWS * F16_LDB + t * 32);
-                // (the nine k-steps are written out: with the piece selected by a switch on the loop counter the compiler kept
-                // every fragment array in scratch memory)
-#define F16_KSTEP(T)                                                                                                  \
-                {                                                                                                             \
-                    if ((T) + F16_PF < 9) {                                                                                   \
-                        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                         \
-                            fr[((T) + F16_PF) % 9][u] = *reinterpret_cast<const h16x8*>(ar + u * AFF_ROWS * F16_LDB + ((T) + F16_PF) * 32); \
-                    }                                                                                                         \
-                    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                             \
-                        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-                            if ((T) == 0) {                                                                                   \
-                                f32x16 z;                                                                                     \
-                                _Pragma("unroll") for (int r = 0; r < 16; ++r) z[r] = 0.f;                                    \
-                                c[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0][u], bq[i][0], z, 0, 0, 0);             \
-                            } else {                                                                                          \
-                                c[u][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[T][u], bq[i][T], c[u][i], 0, 0, 0);       \
-                            }                                                                                                 \
-                        }                                                                                                     \
-                    __builtin_amdgcn_sched_barrier(0);                                                                        \
-                }
-                F16_KSTEP(0) F16_KSTEP(1) F16_KSTEP(2) F16_KSTEP(3) F16_KSTEP(4) F16_KSTEP(5) F16_KSTEP(6) F16_KSTEP(7) F16_KSTEP(8)
-#undef F16_KSTEP
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u >= nt) break;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        // 16 compares per lane, collected as 16 bits of the lane's own halfword: bits = 2 bits + (estimate >= tau) by
-                        // v_cmp + add-with-carry (two VALU instructions per pair, no SGPR round trip; r = 0 ends up in bit 15).
-                        // NaN-safe "upper estimate >= tau": v_cmp_nlt is true for a non-finite estimate - the exact pass decides
-                        // (r = 0 in plain C: the compiler's hazard recognizer places the MFMA-result -> VALU wait states, which it
-                        // cannot do for operands it only sees inside an asm statement)
-                        unsigned bits = !(c[u][i][0] < my_tau[i]) ? 1u : 0u;
-#pragma unroll
-                        for (int r = 1; r < 16; ++r)
-                            asm("v_cmp_nlt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-                                : "+v"(bits) : "v"(c[u][i][r]), "v"(my_tau[i]) : "vcc");
-                        if ((b0 + i) * 32 < p.HW)
-                            reinterpret_cast<unsigned short*>(p.mask)[(((size_t)(b0 + i) * p.total_tiles + tl + u) << 6) + lane] = (unsigned short)bits;
-                    }
-                }
-                // ---- end of PAIR BODY
+            for (int g = 0; g < F16_STAGE; g += 2, ar += 2 * TILEB) {
+                // tile g into set A behind the compares of tile g - 1 (set B; for g = 0 the last tile of the previous stage),
+                // tile g + 1 into set B behind the compares of tile g
+                F16P_TILE(cA, cB, ar, ar + TILEB, true, tile + g - 1, (s > 0 || g > 0) && tile + g - 1 < t_end)
+                F16P_TILE(cB, cA, ar + TILEB, ar + 2 * TILEB, g + 2 < F16_STAGE, tile + g, tile + g < t_end)
             }
         }
-        F16_STASH(&Ah[(s + 1) & 1][0])
-        __syncthreads();
+        if (!(DBG & 4)) {
+            F16_STASH(&Ah[(s + 1) & 1][0])
+            __syncthreads();
+        }
     }
+    if (active) {                                                // the last tile's compares have no MFMAs to hide behind
+        const int lt = t_begin + (nst - 1) * F16_STAGE + F16_STAGE - 1;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int m = 1; m < 2 + 8 * NQB; ++m) { F16P_COMPARE(cB, m, lt, lt < t_end) }
+    }
+    if ((DBG & 8) && sink == 0x12345u) mask16[0] = (unsigned short)sink;
+#undef F16P_TILE
+#undef F16P_KSTEP
+#undef F16P_COMPARE
 #undef F16_FETCH
 #undef F16_STAGE_SETUP
 #undef F16_FETCH_ONE
@@ -643,6 +662,18 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     // pass 1: every tile, the caller's bound
     a.only = nullptr; a.flag_out = a.flag1;
     if (g_prof_ev[0]) (void)hipEventRecord(g_prof_ev[0], s);       // tools: bracket the pass-1 filter (xmem_affinity_profile_events)
+#ifdef XMEM_TOOLS
+    // knock-outs of the pipelined kernel (wrong results, timing only): 1 no row fetch after the first stage, 4 no LDS stage
+    // hand-over (stash + barrier), 8 no bit-matrix stores
+    const int dbg = getenv("XMEM_F16_DBG") ? atoi(getenv("XMEM_F16_DBG")) : 0;
+#define F16P_DBG_CASE(D)                                                                                              \
+    if (dbg == (D)) {                                                                                                 \
+        if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<false, 8, D>), fgrid, dim3(512), 0, s, a);         \
+        else hipLaunchKernelGGL((affinity_filter16_kernel<false, 4, D>), fgrid, dim3(256), 0, s, a);                 \
+    } else
+    F16P_DBG_CASE(1) F16P_DBG_CASE(4) F16P_DBG_CASE(5) F16P_DBG_CASE(8) F16P_DBG_CASE(13)
+#undef F16P_DBG_CASE
+#endif
     if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<false, 8>), fgrid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((affinity_filter16_kernel<false, 4>), fgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
