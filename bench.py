@@ -43,6 +43,12 @@ from xmem2_amd.launch import shard_videos, spawn_ranks          # noqa: E402,F40
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0          # dense v_mfma_f32_32x32x16_f16 peak (~2.5 PF)
+# What a register-only loop of independent MFMA chains sustains chip-wide on RANDOM operands (the chip clocks to its power budget:
+# MI355X_MICROARCH.md "DVFS give-back"); measured by tools/probes/mfma_shadow/mfma_sustained.hip on the round-4 box, output in
+# profiles/r04_mfma_probes.txt (fp16: 1494-1672, fp32: 130-145 TFLOP/s; 0.90-0.95 / 0.99 of nominal on all-zero operands).
+# Reported beside the nominal peaks as the ceiling a kernel built on that instruction has on real data; `frac` stays nominal.
+SUSTAINED_F16_MFMA_TFLOPS = 1600.0
+SUSTAINED_FP32_MFMA_TFLOPS = 140.0
 F16_K = 144                            # contraction length of the fp16 filter (128 terms + 16 augmentation terms)
 CK, CV, TOPK = 64, 512, 30
 BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
@@ -898,6 +904,14 @@ def main():
             # the opt-in modes on the same workload, each as its own labelled key (never the headline): child copies of this command
             for mode, label in (('fp32x', 'value_fp32x'), ('fp16', 'value_fp16_loop')):
                 line[label] = run_mode_child(args, mode)
+        for key, sus in (('roofline', SUSTAINED_F16_MFMA_TFLOPS), ('conv_roofline', SUSTAINED_FP32_MFMA_TFLOPS)):
+            r = line.get(key)
+            if r and r.get('achieved'):
+                r['peak_sustained_random_operands'] = sus
+                r['frac_of_sustained'] = r['achieved'] / sus
+                if r.get('achieved_median'):
+                    r['frac_of_sustained_median'] = r['achieved_median'] / sus
+                r['peak_sustained_source'] = 'tools/probes/mfma_shadow/mfma_sustained.hip -> profiles/r04_mfma_probes.txt'
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -214,6 +214,35 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // epilogue store mode (uniform): 0 raw accumulators, 1 split-K partials, 2 scale / shift (/ relu), 3 the same + residual
+    const int mode = p.raw ? 0 : (p.splitk > 1 ? 1 : (p.res ? 3 : 2));
+    const bool half_io = (HALF == 2) && mode >= 2;                        // activations (output and residual) are halfs; ldout / ldres count halfs
+    // Small tiles request their residual values HERE, ahead of the operand tiles: the short-K pointwise layers (64 -> 256 at
+    // 1/4 resolution: two k-tiles) are bound by memory round trips per workgroup, and a residual fetched in the epilogue adds a
+    // whole one after the last MFMA (the same lane / row mapping as the epilogue below).
+    constexpr bool EARLY_RES = TM * TN <= 2;
+    float rve[EARLY_RES ? TM * TN : 1][16];
+    if (EARLY_RES && mode == 3) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n0 + wn * 32 * TN + j * 32 + l31, p.Cout - 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * 32 * TM + i * 32 + 4 * lh;
+                const int mr = p.res_mod ? mb % p.res_mod : mb;
+                const bool wrap_ok = p.res_mod >= 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = (r & 3) + 8 * (r >> 2);
+                    int t = mr + o;
+                    if (p.res_mod) { if (wrap_ok) { if (t >= p.res_mod) t -= p.res_mod; } else t = (mb + o) % p.res_mod; }
+                    if (half_io) rve[i * TN + j][r] = (mb + o < p.M) ? (float)reinterpret_cast<const _Float16*>(p.res)[(size_t)t * p.ldres + n] : 0.f;
+                    else rve[i * TN + j][r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
+                }
+            }
+        }
+    }
+
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
         store_tile(0);
@@ -280,10 +309,8 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
     // epilogue: lane owns output channel n (col) and 16 pixels (rows) per 32x32 tile.  The store mode is uniform, so it is
     // decided once and each 32x32 block runs straight-line code: all residual loads of a block are issued together
     // (one memory round trip per block instead of one per element) before the fused scale / shift / add / relu and stores.
-    const int mode = p.raw ? 0 : (p.splitk > 1 ? 1 : (p.res ? 3 : 2));
     float* const obase = (mode == 1) ? p.partial + (size_t)blockIdx.z * p.M * p.Cout : gout;
     const long ldo = (mode == 1) ? (long)p.Cout : (long)p.ldout;
-    const bool half_io = (HALF == 2) && mode >= 2;                        // activations (output and residual) are halfs; ldout / ldres count halfs
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * 32 * TN + j * 32 + l31;
@@ -296,7 +323,10 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
             float* const orow = obase + (size_t)mb * ldo + n;
             _Float16* const orow_h = reinterpret_cast<_Float16*>(obase) + (size_t)mb * ldo + n;
             float rv[16];
-            if (mode == 3) {
+            if (EARLY_RES && mode == 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = rve[i * TN + j][r];
+            } else if (mode == 3) {
                 int mr = p.res_mod ? mb % p.res_mod : mb;                 // broadcast residual: row index modulo one image
                 const bool wrap_ok = p.res_mod >= 32;
 #pragma unroll
@@ -1053,7 +1083,8 @@ static bool conv_is_one(const ConvArgs& a) {
 
 template <int BM, int BN, int TM, int TN, int BK, bool G>
 int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = false, int half = 0) {
-    const size_t lds = 2 * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
+    // (a workgroup that contracts a single k-tile never touches the second buffer: half the LDS, twice the resident workgroups)
+    const size_t lds = (a.kt_per_split == 1 ? 1 : 2) * (size_t)(BM + BN) * (BK + 4) * sizeof(float);
     auto kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false, false>;
     if (half && BK == 32) {                        // fp16 loop: half operands (HALF 1: fp32 output, 2: half output + residual)
         const bool one = !G && conv_is_one(a);
