@@ -173,14 +173,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
             }
             bq[i][t] = v;
         }
-        my_tau[i] = ok ? p.tau[q] : INFINITY;                    // (no bound: -inf keeps every pair, see the kernel above)
+        // a query without a bound (-inf) keeps every pair: its list fills up, flags the tile, and the tighten pass makes a bound;
+        // padding queries (+inf) keep none
+        my_tau[i] = ok ? p.tau[q] : INFINITY;
     }
 
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(p.total_tiles, t_begin + p.tiles_per_split);
     const int nst = (t_end - t_begin + F16_STAGE - 1) / F16_STAGE;
 
-    // stage fetch: as in the kernel above (9 pieces of 16 bytes per thread; FAST stage = one contiguous range)
+    // one stage = F16_STAGE tiles x 32 rows x 18 pieces of 16 bytes = 9 pieces per thread.  Row index clamped into the segment
+    // (the duplicated rows of a segment's last tile set spurious bits; the scan drops rows past the segment's end); the segment
+    // table is copied to scalars once; tiles past the split's end repeat its last tile - branch-free loads, their bits are not stored.
+    // FAST stage (the rule; decided per stage with scalar arithmetic): its tiles lie in one segment, none is the segment's clamped
+    // last tile and none is past the split - the stage is F16_STAGE x 9216 contiguous bytes, piece e at byte 16 e
     static_assert(XMEM_MAX_SEGMENTS == 4, "segment select below is written out for 4 segments");
     const int gt1 = 1 < p.n_seg ? p.seg[1].tile0 : 0x7fffffff, gt2 = 2 < p.n_seg ? p.seg[2].tile0 : 0x7fffffff,
               gt3 = 3 < p.n_seg ? p.seg[3].tile0 : 0x7fffffff;
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
     // PT, stored when PTOK) behind its MFMAs; the fragment of step T + F16_PF is requested first - for the last steps of a tile
     // that is a first fragment of the NEXT tile of the same stage (ARN; the stage's last tile has no successor before the barrier)
 #define F16P_COMPARE(PRV, M, PT, PTOK)                                                                                \
-    if (!(DBG & 2)) {                                                                                                 \
+    {                                                                                                                 \
         /* consume: the two lane masks slot M - 1 produced are shifted into their array's halfword (bit 15 - r <-> r) */   \
         if ((M) >= 2 && (M) < 2 + 8 * NQB) {                                                                          \
             const int a_ = ((M) - 2) >> 3, e_ = (((M) - 2) & 7) * 2;                                                  \
