@@ -51,6 +51,9 @@ SUSTAINED_F16_MFMA_TFLOPS = 1600.0
 SUSTAINED_FP32_MFMA_TFLOPS = 140.0
 F16_K = 144                            # contraction length of the fp16 filter (128 terms + 16 augmentation terms)
 CK, CV, TOPK = 64, 512, 30
+CLEAR_MARGIN = 2e-2                    # the tests' gate (tests/test_gpu_e2e.py): 2x the reference's own 8-vs-1-thread probability noise
+TIGHT_MARGIN = 2e-3                    # SURVEY 8(c)'s acceptance margin, reported beside it
+SCHEMA = 5                             # meaning of the keys of the JSON line; see `schema_note` in the line
 BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
 
 PRECISION_LABEL = {'fp32': '',
@@ -272,7 +275,7 @@ def run_gpu(args, device, rank, world):
     # ---- instrumented pass (rank 0): the SAME schedule again (graphs, two streams, batched hints) with HIP events on
     # the launch stream around the memory-readout calls, which are eager launches between the captured stages
     taps, inst_frames, inst_elapsed = {}, 0, None
-    if rank == 0 and not args.traced_child:
+    if rank == 0 and not args.traced_child and not args.scale_only:
         inst_frames = min(args.steps, 100)
         ops.EVENT_TAP = []
         torch.cuda.synchronize(device)
@@ -292,7 +295,7 @@ def run_gpu(args, device, rank, world):
     # of the readout (list lengths, query tiles that needed the second pass): a few more frames of the same schedule, with a
     # device sync per frame (not part of any reported rate)
     filt, cand = None, None
-    if rank == 0 and not args.traced_child:
+    if rank == 0 and not args.traced_child and not args.scale_only:
         import ctypes as C
         from xmem2_amd._lib import load
         lib = load()
@@ -338,7 +341,7 @@ def run_gpu(args, device, rank, world):
     # eagerly with ops.RECORD on (every conv2d call notes its shape, plan, algorithmic FLOPs and the MFMA FLOPs that plan issues:
     # direct form padded to its tile, F(2x2) 16 / F(4x4) 36 position GEMMs); not part of any reported rate
     conv_survey = None
-    if rank == 0 and not args.traced_child:
+    if rank == 0 and not args.traced_child and not args.scale_only:
         start = ((args.warmup + args.steps + inst_frames + 400) // KB + 1) * KB
         hint(start)                                                  # consumed by the recorded frames; ITS convolutions are not recorded
         ops.RECORD = []
@@ -544,8 +547,8 @@ def run_cpu_baseline(res, args, device):
         gpu_out.append((ops.argmax_u8(pg).cpu().numpy(), pg[:, 4::8, 4::8].cpu()))
     gpu.cancel_prefetch()
     del dev
-    ious, mism, perr, clear_mism, near_tie = [], 0, 0.0, 0, 0
-    cpu_masks = []
+    ious, mism, perr, clear_mism, near_tie, tight_mism = [], 0, 0.0, 0, 0, 0
+    cpu_masks, cpu_probs = [], []
     pos = [0]
 
     def cpu_frames(n):
@@ -558,13 +561,16 @@ def run_cpu_baseline(res, args, device):
             ts.append(time.perf_counter() - t0)
             g, pg = gpu_out[i]
             cpu_masks.append(np.asarray(m))
+            cpu_probs.append(p[:, 4::8, 4::8].clone())
             ious.append(R.compute_array_iou(g, m))
-            nonlocal mism, perr, clear_mism, near_tie
+            nonlocal mism, perr, clear_mism, near_tie, tight_mism
             mism += int((g != m).sum())
             perr = max(perr, float((pg - p[:, 4::8, 4::8]).abs().max()))
             top2 = torch.topk(p, 2, dim=0).values                       # the CPU path's own top-2 margin per pixel
             margin = (top2[0] - top2[1]).numpy()
-            clear_mism += int(((g != np.asarray(m)) & (margin > 5e-2)).sum())
+            diff = (g != np.asarray(m))
+            clear_mism += int((diff & (margin > CLEAR_MARGIN)).sum())
+            tight_mism += int((diff & (margin > TIGHT_MARGIN)).sum())
             near_tie += int((margin < 1e-2).sum())
         return ts
 
@@ -578,6 +584,28 @@ def run_cpu_baseline(res, args, device):
     cpu_frames(3)
     ts = cpu_frames(args.cpu_frames)
     floor = None
+    if wl['K'] == 1:
+        # the reference path's own thread-count noise on exactly these frames: the same oracle again at ONE
+        # other fixed thread count (8, or 32 when the run above settled on 8) - the figure the GPU-vs-CPU numbers are to be read against
+        t2 = 8 if best_t != 8 else min(32, all_threads)
+        torch.set_num_threads(t2)
+        ref2 = R.RefCore(R.RefNet(res['sd']), cfg)
+        ref2.set_all_labels(labels)
+        for j in range(wl['perm']):
+            ref2.put_to_permanent_memory(torch.from_numpy(fr[j]), torch.from_numpy(mk[j]))
+        two, perr2 = [], 0.0
+        for i in range(len(cpu_masks)):
+            p2 = ref2.step(cpu_frame(i), None, None)
+            two.append(np.asarray(R.post_process(p2)))
+            perr2 = max(perr2, float((cpu_probs[i] - p2[:, 4::8, 4::8]).abs().max()))
+        A, B = np.stack(cpu_masks), np.stack(two)
+        floor = dict(frames=len(two), second_run_threads=t2,
+                     first_run_threads=f'sweep {sweep} over the first {sum(w + k for _, w, k in plan)} frames, then {best_t}',
+                     argmax_mismatch_pixels=int((A != B).sum()), pixels=int(A.size),
+                     mask_iou_min=float(min(R.compute_array_iou(a, b) for a, b in zip(cpu_masks, two))),
+                     max_abs_prob_err_ds8=perr2,
+                     note='oracle vs oracle at another thread count on the same frames: the reference path\'s own noise; read '
+                          'argmax_mismatch_pixels / max_abs_prob_err_ds8 of `parity` against these')
     if wl['K'] > 1:
         # multi-object streams: the reference path's OWN thread-count noise on exactly these frames next
         # to the GPU figures - the same oracle again at 1 thread (the goldens' count) vs the run above (thread sweep, then best_t)
@@ -608,7 +636,8 @@ def run_cpu_baseline(res, args, device):
                        f'best count ({best_t} threads); oracle/cpu_ref.py; host has {os.cpu_count()} logical CPUs'), \
         dict(mask_iou_vs_cpu_min=float(min(ious)), mask_iou_vs_cpu_mean=float(np.mean(ious)), argmax_mismatch_pixels=mism,
              frames_compared=len(ious), pixels_per_frame=wl['H'] * wl['W'], max_abs_prob_err_ds8=perr,
-             argmax_mismatch_pixels_at_clear_cpu_margin=clear_mism, clear_margin=5e-2,
+             argmax_mismatch_pixels_at_clear_cpu_margin=clear_mism, clear_margin=CLEAR_MARGIN,
+             argmax_mismatch_pixels_at_survey_margin=tight_mism, survey_margin=TIGHT_MARGIN,
              cpu_pixels_near_tie_fraction=near_tie / max(len(ious) * wl['H'] * wl['W'], 1), near_tie_margin=1e-2,
              **({'oracle_thread_noise_floor': floor} if floor is not None else {}))
 
@@ -660,9 +689,10 @@ def parse_args(argv=None):
     ap.add_argument('--workload', default='b32', choices=sorted(WORKLOADS))
     ap.add_argument('--cpu-frames', type=int, default=20, help='timed frames of the CPU baseline at its best thread count')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'fp16', 'fp16w', 'fp32x'],
-                    help='fp16 = the opt-in reduced-precision mode (Winograd-domain operands in fp16, fp32 accumulation; SURVEY 8f-4); '
-                         'fp32x = the split-operand experiment (every fp32 GEMM operand carried as two halfs, four partial products on the '
-                         'fp16 MFMA, fp32 accumulation: fp32-class results).  Both are reported under their own metric label, never the headline')
+                    help='opt-in modes, each reported under its own metric label, never the headline: fp16 = the fp16 loop (half activations in HBM, '
+                         'half-operand direct convolutions on the fp16 MFMA, fp32 accumulate; the reference\'s autocast mode, SURVEY 8f-4); fp16w = only the '
+                         'F(2x2) Winograd-domain operands in fp16; fp32x = every fp32 GEMM operand carried as two halfs, four partial products on the fp16 '
+                         'MFMA, fp32 accumulation (fp32-class results)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefetch', action='store_true', help='do not pipeline the coming frames\' key encoder')
     ap.add_argument('--key-batch', type=int, default=4, help='frames per batched key-encoder hint (prefetch_keys)')
@@ -673,13 +703,21 @@ def parse_args(argv=None):
     ap.add_argument('--keep-trace', default=None, help='directory to keep the child\'s kernel_trace.csv in')
     ap.add_argument('--traced-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-extra-modes', action='store_true', help='skip the child runs that add value_fp32x / value_fp16_loop to the default line')
-    ap.add_argument('--dist-backend', default='gloo', help='control-plane backend for the timing barrier / reductions '
-                    '(nccl = RCCL; the data path has no collective)')
+    ap.add_argument('--dist-backend', default='gloo', help='control plane of the timing barrier / scalar reductions (the data path has no '
+                    'collective).  gloo (default): every rank sees only its own GPU (device isolation as xmem2_amd.launch), reductions on the '
+                    'host.  nccl: RCCL control plane, every device stays visible to every rank')
+    ap.add_argument('--scale-only', action='store_true', help='only the timed region and the JSON line: no traced child, no opt-in mode children, '
+                    'no un-hinted pass, no instrumented passes, no CPU baseline (what a multi-GPU scaling run needs; implied on ranks != 0)')
     return ap.parse_args(argv)
 
 
 def main():
     args = parse_args()
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.gpus > 1:
+        args.scale_only = True                     # a scaling run measures the timed region only, on every rank alike
+    if args.scale_only:
+        args.no_cpu_baseline = args.no_kernel_trace = args.no_extra_modes = True
+        args.plain_steps = 0
     torch.set_grad_enabled(False)
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
@@ -712,7 +750,9 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:                                   # one process per GPU: cores next to the GPU, a bounded intra-op thread pool
         from xmem2_amd.launch import pin_rank
-        pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), max_threads=8, device_index=dev_index)
+        pin = pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), max_threads=8, device_index=dev_index)
+    else:
+        pin = None
     backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -734,11 +774,18 @@ def main():
                 backend = 'gloo'
         if backend != 'nccl':
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get('XMEM_MAIN_CUS'):            # measurement knob: "first:count" - the main stream on a CU subset (see ops.masked_stream)
+        from xmem2_amd import ops as _ops
+        first, count = (int(v) for v in os.environ['XMEM_MAIN_CUS'].split(':'))
+        torch.cuda.set_stream(_ops.masked_stream(device, count, first))
     res = run_gpu(args, device, rank, world)
     elapsed = max_over_ranks(res['elapsed'], device)
     total_frames = sum_over_ranks(args.steps, device)
     per_rank = [args.steps / e for e in gather_over_ranks(res['elapsed'], device)]
     preload_all = gather_over_ranks(res['preload_s'], device)
+    pinned_cpus = gather_over_ranks((pin or {}).get('cpus') or 0, device)
+    host_threads = gather_over_ranks(torch.get_num_threads(), device)
+    visible = gather_over_ranks(torch.cuda.device_count(), device)
     fps = total_frames / elapsed
     if args.traced_child:
         print(json.dumps({'traced_child': True, 'fps_under_tracer': fps, 'steps': args.steps}), flush=True)
@@ -770,6 +817,15 @@ def main():
                        'parallelism': f'{world} independent streams, no collectives',
                        'control_plane': backend or 'none'},
             'per_rank_fps': per_rank,
+            'per_rank_host': {'pinned_cpus': [int(v) for v in pinned_cpus], 'torch_threads': [int(v) for v in host_threads],
+                              'visible_devices': [int(v) for v in visible],
+                              'note': 'pinned_cpus 0 = not pinned (one rank, or no sched_setaffinity); with the gloo control plane every rank '
+                                      'sees exactly one device'},
+            'schema': SCHEMA,
+            'schema_note': 'schema 5 (round 5): roofline.frac = F_sim / mean duration of the filter kernel in the marker-cut trace / 2.5 PF (as round 4); '
+                           'roofline.call_frac = F_sim / the whole select call (all its launches, trace) / 2.5 PF (new); conv_roofline.achieved/frac = '
+                           'EXECUTED MFMA FLOPs / conv family time / the peak of the pipe the mode runs on (fp32: 157.3 TF; fp16 / fp32x / fp16w modes: 2.5 PF - '
+                           'round 4 divided every mode by 157.3); parity.clear_margin = 2e-2 (round 4: 5e-2) and parity.survey_margin = 2e-3',
             'roofline': {'bound': 'mfma',
                          'kernel': 'affinity_filter16_kernel<false, 4|8> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
                                    'of model/memory_util.py:7-39 on v_mfma_f32_32x32x16_f16 with augmented fp16 operands (the result is a rigorous '
@@ -833,9 +889,13 @@ def main():
                     ctf = alg['conv'] / (conv_us * 1e-3)
                     cs = res.get('conv_survey')
                     etf = (cs['executed_mfma_gflop_per_frame'] / (conv_us * 1e-3)) if cs else None
+                    # the pipe the mode's convolutions run on: fp32 MFMA, or the fp16 MFMA (fp32x executes four half products per fp32 product)
+                    conv_peak = PEAK_FP32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_F16_MFMA_TFLOPS
+                    if etf and args.precision == 'fp32x':
+                        etf *= 4.0
                     line['conv_roofline'] = {'bound': 'mfma', 'kernel': 'xmem_conv2d_nhwc: conv_mfma_kernel / gemm_stream_kernel (Winograd-domain position GEMMs) + transform kernels',
-                                             'achieved': etf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                             'frac': (etf / PEAK_FP32_MFMA_TFLOPS) if etf else None,
+                                             'achieved': etf, 'peak': conv_peak, 'unit': 'TFLOP/s',
+                                             'frac': (etf / conv_peak) if etf else None,
                                              'executed_mfma_gflop_per_frame': cs['executed_mfma_gflop_per_frame'] if cs else None,
                                              'executed_by_form': cs['forms'] if cs else None,
                                              'algorithmic_tflops': ctf, 'algorithmic_speed_vs_fp32_peak': ctf / PEAK_FP32_MFMA_TFLOPS,
@@ -849,6 +909,9 @@ def main():
                                                      'or 1/4 of those FLOPs), not a roofline fraction'}
                 if aff_us:
                     line['roofline']['timed_region_trace_us_per_frame'] = aff_us
+                    # the SELECT as a whole (every launch of the call: bound, filter, scan / lists, refine) against the pipe its contraction runs on
+                    line['roofline']['call_frac'] = (aff_gf / (aff_us * 1e-3)) / PEAK_F16_MFMA_TFLOPS
+                    line['roofline']['call_tflops'] = aff_gf / (aff_us * 1e-3)
                     line['roofline']['frac_fp32_equivalent_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS
                     ks = {}
                     for k, v in tr['kernels'].items():
@@ -904,7 +967,8 @@ def main():
             # the opt-in modes on the same workload, each as its own labelled key (never the headline): child copies of this command
             for mode, label in (('fp32x', 'value_fp32x'), ('fp16', 'value_fp16_loop')):
                 line[label] = run_mode_child(args, mode)
-        for key, sus in (('roofline', SUSTAINED_F16_MFMA_TFLOPS), ('conv_roofline', SUSTAINED_FP32_MFMA_TFLOPS)):
+        for key, sus in (('roofline', SUSTAINED_F16_MFMA_TFLOPS),
+                         ('conv_roofline', SUSTAINED_FP32_MFMA_TFLOPS if args.precision == 'fp32' else SUSTAINED_F16_MFMA_TFLOPS)):
             r = line.get(key)
             if r and r.get('achieved'):
                 r['peak_sustained_random_operands'] = sus

@@ -27,6 +27,8 @@ def main():
     sd = synthetic_state_dict(0)
     ref_net = cpu_ref.RefNet(sd)
     clips = [U.c3_clip(), U.golden_clip('240p_2obj', (240, 427), 2)]
+    if len(sys.argv) > 1:                                        # e.g. `parity_by_plan.py 240p_2obj`: only the named clips
+        clips = [c for c in clips if c.name in sys.argv[1:]]
     print(f'device {torch.cuda.get_device_name(0)}; oracle threads: 1 (the goldens\' count) and 8; host cores {os.cpu_count()}')
     for clip in clips:
         t0 = time.time()
@@ -39,7 +41,9 @@ def main():
         print(f'\n== {clip.name}: {clip.t} frames {clip.hw}, objects {clip.labels}, consolidation at step {first_lt} (oracle runs {time.time() - t0:.0f} s)')
         for name, lo, hi in spans:
             print(f'   {name:26s} oracle(8 thr) vs oracle(1 thr): {U.fmt(U.compare(o8, o1, clip.labels, lo, hi))}')
-        for form, label in ((None, 'shipped plans (F(4x4)+F(2x2)+direct)'), ('f2', 'F(4x4) -> F(2x2)'), ('direct', 'direct form everywhere')):
+        for form, label in ((None, 'shipped plans (F(4x4)+F(2x2)+direct)'), ('f2', 'F(4x4) -> F(2x2)'), ('direct', 'direct form everywhere'),
+                            ('direct_sk2', 'direct form, every contraction summed in 2 slabs'),
+                            ('direct_sk3', 'direct form, every contraction summed in 3 slabs')):
             ops.CONV_FORM = form
             net = XMem({'key_dim': 64, 'value_dim': 512, 'hidden_dim': 64}, None).to('cuda').eval()
             net.load_weights(sd)

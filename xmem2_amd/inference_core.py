@@ -140,7 +140,7 @@ class InferenceCore:
             raise ValueError('prefetch_keys: all frames of a batch must have the same shape')
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=net.device)
+            self._side = ops.side_stream(net.device)
         B = len(images)
         par = self._group_parity.get(B, 1) ^ 1                   # two buffer groups per batch size, used alternately
         gid = ('g', B, par)

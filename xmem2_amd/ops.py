@@ -254,7 +254,7 @@ def winograd4_weights(w):
 WINO4_MIN_PIXELS = int(os.environ.get('XMEM_WINO4_MIN_PIXELS', '4096'))   # applies to F(2x2) entries of the plan table only
 WINO4 = os.environ.get('XMEM_WINO4', '1') != '0'
 # Tools knob (parity attribution, tools/parity_by_plan.py): 'direct' runs every convolution in the direct implicit-GEMM form,
-# 'f2' replaces F(4x4) by F(2x2); None / '' = the shipped plan table.  Read at call time so that a tool can switch it.
+# 'f2' replaces F(4x4) by F(2x2), 'direct_sk2' / 'direct_sk3' = the direct form summed in 2 / 3 slabs; None / '' = the shipped plan table.  Read at call time so that a tool can switch it.
 CONV_FORM = os.environ.get('XMEM_CONV_FORM') or None
 
 
@@ -599,6 +599,10 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
         d.scale = cw.scale_sp.data_ptr()
     if plan is None and CONV_FORM == 'direct' and _PRECISION == 'fp32':
         plan, explicit = (0, 0), True            # the library's deterministic direct-form heuristic
+    elif plan is None and CONV_FORM in ('direct_sk2', 'direct_sk3') and _PRECISION == 'fp32':
+        # the direct form with every contraction cut into 2 / 3 slabs that are summed afterwards: the SAME products in another fp32
+        # summation order (tests/parity_by_plan.py: how much of a parity margin is the order of additions alone)
+        plan, explicit = (3, int(CONV_FORM[-1])), True
     if plan is None:
         plan = _lookup_plan(key, split)
     if plan is None:
@@ -671,6 +675,34 @@ def conv2d(x, cw, out=None, out_ld=None, res=None, relu_in=False, relu_out=False
                                                       B, Ho, Wo, cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad, plan[0],
                                                       bool(d.w_winograd) and out_ld % 4 == 0 and (res is None or res.shape[-1] % 4 == 0))))))
     return out
+
+
+_HIPRT = None
+
+
+def masked_stream(device, n_cus, first=0):
+    """A HIP stream whose kernels may only run on `n_cus` compute units (hipExtStreamCreateWithCUMask), wrapped for torch.
+    The mask's bits are dealt round-robin over the 8 XCDs by the driver, so the low n_cus bits are n_cus / 8 CUs of every XCD.
+    Measurement knob for the frame pipeline's side stream (XMEM_SIDE_CUS); the default stream of a core is unmasked."""
+    global _HIPRT
+    if _HIPRT is None:
+        _HIPRT = C.CDLL('libamdhip64.so')
+    words = (first + n_cus + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for b in range(first, first + n_cus):
+        mask[b // 32] |= (1 << (b % 32))
+    st = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = _HIPRT.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError(f'hipExtStreamCreateWithCUMask failed with status {rc}')
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
+def side_stream(device):
+    """The stream `InferenceCore.prefetch_keys` runs the batched key encoder on."""
+    n = int(os.environ.get('XMEM_SIDE_CUS', '0') or 0)
+    return masked_stream(device, n) if n > 0 else torch.cuda.Stream(device=device)
 
 
 def trace_marker(tag=0):
