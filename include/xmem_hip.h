@@ -95,7 +95,10 @@ typedef struct {
     const void* w_winograd4_split;
     /* FP16 LOOP (config['precision'] = 'fp16', opt-in, never the default; mirrors the reference's GPU mode: torch.cuda.amp.autocast
      * around the frame loop, inference/run_on_video.py:76, fp32 preload :59-66).  in_half = 1: `in` is [B][H][W][ldin] IEEE halfs
-     * (Cin % 8 == 0, ldin % 8 == 0, 16-byte aligned) and w_half holds the weights [Cout][KH][KW][Cin] as halfs; the contraction runs
+     * (Cin % 8 == 0, ldin % 8 == 0, 16-byte aligned) and w_half holds the weights [Cout][KH][KW][Cin] as halfs.  ZERO-PADDING
+     * CONTRACT: the kernel reads all Cin (the layer's channel count padded to 8) halfs of every pixel; a caller whose layer has
+     * fewer true channels keeps the padding channels of `in` ZERO (finite is not enough of a promise: the zero weights there would turn
+     * an Inf / NaN into NaN), and a channel slice of a wider buffer holds a multiple of 8 channels and ends inside its pixel.  The contraction runs
      * on v_mfma_f32_32x32x16_f16 in the DIRECT form (no Winograd: plan_tile 1..3 / 0) with fp32 accumulation and an fp32 epilogue.
      * out_half = 1: `out` and `res` are halfs too (ldout / ldres count halfs; the result is rounded once, to nearest even);
      * out_half = 0 stores fp32 (key projection, mask head).  plan_tile 23..40, arith and the Winograd operands are ignored. */

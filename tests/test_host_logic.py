@@ -346,3 +346,102 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
         assert not bad, f'{src}: kernels with scratch memory (bytes per lane): {bad}'
         n_kernels += len(names)
     assert n_kernels > 100
+
+
+def test_filter_kernel_compares_keep_their_distance_from_the_mfma_that_wrote_them(tmp_path):
+    """csrc/affinity_filter.hip: the software-pipelined compares read MFMA accumulator VGPRs from inline asm, which the hazard
+    recognizer does not see; the MFMA -> VALU read hazard is met by PLACEMENT only (the asm statements are volatile and
+    sched_barriers pin the slots).  Checked on the disassembly of every affinity_filter16_kernel instantiation: whenever a
+    v_cmp_nlt_f32 reads a VGPR that a v_mfma_f32_32x32x16_f16 earlier in the same straight-line stretch wrote, at least three
+    other MFMAs were issued in between (each occupies the in-order pipe for its passes), or at least 30 s_nop wait states."""
+    import re
+    import subprocess
+    from xmem2_amd import build as B
+    llvm = '/opt/rocm/lib/llvm/bin'
+    tools = [os.path.join(llvm, t) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-objdump')]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip('ROCm LLVM binutils not installed')
+    B.build(force=False, verbose=False)
+    obj = os.path.join(B.CSRC, 'affinity_filter.o')
+    fat, co = str(tmp_path / 'fat.bin'), str(tmp_path / 'dev.co')
+    subprocess.run([tools[0], '-O', 'binary', '--only-section=.hip_fatbin', obj, fat], check=True)
+    subprocess.run([tools[1], '--unbundle', '--type=o', f'--input={fat}', f'--targets=hipv4-amdgcn-amd-amdhsa--{B.ARCH}',
+                    f'--output={co}'], check=True)
+    asm = subprocess.run([tools[2], '-d', co], check=True, capture_output=True, text=True).stdout
+    kernels = re.split(r'\n(?=[0-9a-f]+ <)', asm)
+    checked = 0
+    for body in kernels:
+        head = body.split('\n', 1)[0]
+        if 'affinity_filter16_kernel' not in head:
+            continue
+        prog = []                      # (address, instruction text, branch target address | None)
+        for line in body.splitlines()[1:]:
+            m = re.match(r'\s*(\S.*?)\s*//\s*([0-9A-F]+):', line)
+            if not m:
+                continue
+            ins, addr = m.group(1), int(m.group(2), 16)
+            tgt = None
+            if ins.startswith(('s_cbranch', 's_branch')):
+                off = int(ins.split()[1], 0)
+                tgt = addr + 4 + 4 * (off - 65536 if off >= 32768 else off)
+            prog.append((addr, ins, tgt))
+        index = {a: i for i, (a, _, _) in enumerate(prog)}
+        writer = {}                    # vgpr -> (mfma count, nop wait states) when an MFMA last wrote it
+        cnt = {'mfma': 0, 'nop': 0}
+
+        def visit(ins):
+            nonlocal checked
+            op = ins.split()[0]
+            if op == 's_nop':
+                cnt['nop'] += int(ins.split()[1], 0) + 1
+            elif op.startswith('v_mfma_'):
+                m = re.search(r'v\[(\d+):(\d+)\]', ins)
+                cnt['mfma'] += 1
+                for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                    writer[r] = (cnt['mfma'], cnt['nop'])
+            elif op.startswith('v_cmp_nlt_f32'):
+                for r in (int(v) for v in re.findall(r'\bv(\d+)\b', ins)):
+                    if r in writer:
+                        wm, wn = writer[r]
+                        assert (cnt['mfma'] - wm) >= 3 or (cnt['nop'] - wn) >= 30, \
+                            f'{head.strip()}: "{ins}" reads v{r} {cnt["mfma"] - wm} MFMAs / {cnt["nop"] - wn} wait states after the MFMA that wrote it'
+                        checked += 1
+
+        # straight-line walk (forward branches only skip stores / fetches, never MFMAs); a loop body is walked a second time when its
+        # back edge is reached, so that a compare at the top of an iteration is measured against the MFMAs at the end of the previous one
+        for i, (addr, ins, tgt) in enumerate(prog):
+            visit(ins)
+            if tgt is not None and tgt <= addr and tgt in index:
+                for _, ins2, _ in prog[index[tgt]:i + 1]:
+                    visit(ins2)
+    assert checked > 100, checked
+
+
+def test_a_second_host_thread_inside_a_stage_fails_loudly():
+    """ops.precision is a process-wide switch (one host thread drives the kernels of a process): a second thread entering while the
+    first is inside must raise instead of flipping the first thread's arithmetic mode; nesting in one thread and taking turns work."""
+    import threading
+    from xmem2_amd import ops
+    inside, leave, seen = threading.Event(), threading.Event(), {}
+
+    def first():
+        with ops.precision('fp32x'):
+            with ops.precision('fp32'):              # nesting in one thread
+                pass
+            inside.set()
+            leave.wait(10)
+            seen['mode'] = ops._PRECISION
+
+    t = threading.Thread(target=first)
+    t.start()
+    assert inside.wait(10)
+    with pytest.raises(RuntimeError, match='another host thread'):
+        with ops.precision('fp16'):
+            pass
+    assert ops._PRECISION == 'fp32x'                 # untouched by the refused entry
+    leave.set()
+    t.join()
+    assert seen['mode'] == 'fp32x'
+    with ops.precision('fp16'):                      # taking turns is fine
+        assert ops._PRECISION == 'fp16'
+    assert ops._PRECISION == 'fp32'

@@ -260,8 +260,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
         if ((M) >= 2 && (M) < 2 + 8 * NQB) {                                                                          \
             const int a_ = ((M) - 2) >> 3, e_ = (((M) - 2) & 7) * 2;                                                  \
             unsigned long long junk0, junk1;                                                                          \
-            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk0) : "s"(pmk0));                     \
-            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk1) : "s"(pmk1));                     \
+            asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk0) : "s"(pmk0));                     \
+            asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk1) : "s"(pmk1));                     \
             if ((DBG & 8) && e_ == 14) sink ^= bits[a_];                                                              \
             else if (e_ == 14 && (PTOK) && (b0 + a_) * 32 < p.HW)                                                     \
                 mask16[(((size_t)(b0 + a_) * p.total_tiles + (PT)) << 6) + lane] = (unsigned short)bits[a_];          \
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
         if ((M) >= 1 && (M) < 1 + 8 * NQB) {                                                                          \
             const int a_ = ((M) - 1) >> 3, e_ = (((M) - 1) & 7) * 2;                                                  \
             if (e_ == 0) bits[a_] = 0u;                                                                               \
-            asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(pmk0) : "v"(PRV[a_][e_]), "v"(my_tau[a_]));                      \
-            asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(pmk1) : "v"(PRV[a_][e_ + 1]), "v"(my_tau[a_]));                  \
+            asm volatile("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(pmk0) : "v"(PRV[a_][e_]), "v"(my_tau[a_]));                      \
+            asm volatile("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(pmk1) : "v"(PRV[a_][e_ + 1]), "v"(my_tau[a_]));                  \
         }                                                                                                             \
     }
 #define F16P_KSTEP(T, CUR, PRV, AR, ARN, HASN, PT, PTOK)                                                              \

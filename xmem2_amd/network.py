@@ -258,6 +258,11 @@ class XMem:
         is the capturing stream inside torch.cuda.graph, so they are captured like any other launch."""
         prec = self._call_precision or self.precision
         only = os.environ.get('XMEM_PRECISION_ONLY')          # tools: restrict a non-default precision to one stage kind
+        if only and prec == 'fp16':
+            # the fp16 loop keeps HALF activations across stage boundaries (key -> segment -> value): one stage alone cannot run in
+            # another storage type.  The knob is for the operand-only modes (fp16w / fp32x), whose tensors stay fp32.
+            raise RuntimeError("XMEM_PRECISION_ONLY does not compose with precision='fp16' (half activations cross the stage boundaries); "
+                               "use it with 'fp16w' or 'fp32x'")
         if only and prec != 'fp32' and name != only:
             prec = 'fp32'
         if not self.use_graphs or ops.eager_only() or name in os.environ.get('XMEM_EAGER_STAGES', '').split(','):

@@ -141,6 +141,7 @@ def _h(t):
 # precision - the Winograd-domain operands are rounded to fp16 and multiplied on the fp16 MFMA with fp32 accumulation (the
 # counterpart of the reference's autocast loop, inference/run_on_video.py:76).  Set per call tree by XMem (`precision`).
 _PRECISION = 'fp32'
+_DRIVER = threading.RLock()          # held while a thread is inside `precision` (a network stage): see precision.__enter__
 PRECISIONS = ('fp32', 'fp16', 'fp16w', 'fp32x')
 # 'fp16' (opt-in): THE FP16 LOOP - the counterpart of the reference's GPU mode (torch.cuda.amp.autocast around the frame loop,
 # inference/run_on_video.py:76; fp32 preload :59-66): activations are IEEE halfs in HBM, every convolution contracts half
@@ -165,11 +166,19 @@ class precision:
 
     def __enter__(self):
         global _PRECISION
+        # the mode is a process-wide switch and un-scoped scratch is shared per device: ONE host thread may be inside a network stage
+        # at a time (the reference's InferenceCore is single-threaded too).  A second thread entering concurrently is a
+        # contract violation and fails loudly instead of silently flipping the other thread's arithmetic mode; the same thread
+        # may nest, and different threads may take turns.
+        if not _DRIVER.acquire(blocking=False):
+            raise RuntimeError('xmem2_amd.ops: another host thread is inside a network stage - one thread drives the kernels of a process at a '
+                               'time (run one process per stream of videos, xmem2_amd.launch)')
         self.prev, _PRECISION = _PRECISION, self.mode
 
     def __exit__(self, *exc):
         global _PRECISION
         _PRECISION = self.prev
+        _DRIVER.release()
 
 
 class ConvWeights:
@@ -477,6 +486,15 @@ def _conv2d_half(lib, x, cw, out, out_ld, res, relu_in, relu_out, in_ld, cin, pl
         raise RuntimeError(f'conv2d (half): weight expects Cin={cw.cin} (padded {cin_h}), got {cin}')
     if cin_h > ldin:
         raise RuntimeError(f'conv2d (half): the input buffer has {ldin} channels per pixel, the layer reads {cin_h} (pad to a multiple of 8)')
+    if in_ld is not None or cin != cin_h:
+        # a channel SLICE of a wider buffer: the kernel reads cin_h (= Cin padded to 8) halfs from the slice start whatever `cin` says,
+        # and only the zero WEIGHTS mask the tail - 0 x Inf/NaN from a neighbouring slice or an uninitialised tail would be NaN.
+        # So a slice must be a whole number of 8-half groups and must end inside its pixel (include/xmem_hip.h, xmem_conv_desc.in_half).
+        if cin % 8 != 0:
+            raise RuntimeError(f'conv2d (half): a channel slice must hold a multiple of 8 channels, got cin={cin} '
+                               '(pad the slice and zero-fill the padding channels)')
+        if x.storage_offset() % ldin + cin_h > ldin:
+            raise RuntimeError(f'conv2d (half): the slice [{x.storage_offset() % ldin}, +{cin_h}) crosses the pixel stride {ldin}')
     Ho = (H + 2 * cw.pad - cw.kh) // cw.stride + 1
     Wo = (W + 2 * cw.pad - cw.kw) // cw.stride + 1
     odt = out_dtype if out_dtype is not None else (out.dtype if out is not None else torch.float16)
