@@ -152,3 +152,33 @@ def test_select_k_next_best_annotation_candidates_on_files(tmp_path):
         os_masks[-1].unlink()
         select_k_next_best_annotation_candidates(str(imgs), str(msks), str(out), k=1, print_progress=False,
                                                  use_previously_predicted_masks=True, overwrite_config=dict(cfg))
+
+
+def test_selector_hip_reproduces_the_reference_recorded_choices():
+    """tests/golden/selector.npz holds choices recorded from the IMPORTED reference function (frame_selection.py:99-244 behind
+    arithmetic-free import placeholders, masks at key resolution; tests/golden/make_selector_goldens.py) and the oracle's score
+    trace, proven to make the same choices.  The HIP selector must reproduce the scores (fp32 summation order aside) and - wherever
+    the best score leads the runner-up by more than that tolerance - the reference's choices themselves."""
+    import ast
+    from conftest import load_golden
+    from xmem2_amd.frame_selection import select_next_candidates
+    g = load_golden('selector')
+    T = torch.from_numpy
+    n_decisive = 0
+    for name in [str(n) for n in g['names']]:
+        keys, shr, sel = T(g[f'{name}/keys']), T(g[f'{name}/shr']), T(g[f'{name}/sel'])
+        masks = [T(m) for m in g[f'{name}/masks']]
+        kw = ast.literal_eval(str(g[f'{name}/kwargs']))
+        chosen, scores = [int(v) for v in g[f'{name}/chosen']], g[f'{name}/oracle_scores']
+        got = select_next_candidates(keys, shr, sel, masks, device='cuda:0', **kw)
+        decisive = True
+        for it, (a, b) in enumerate(zip(select_next_candidates.last_scores, scores)):
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-7, err_msg=f'{name}: scores of iteration {it}')
+            top = np.sort(b)[::-1]
+            if len(top) > 1 and top[0] - top[1] <= 4e-4 * abs(top[0]):
+                decisive = False
+                break
+        if decisive:
+            assert list(got) == chosen, f'{name}: {got} vs the reference\'s {chosen}'
+            n_decisive += 1
+    assert n_decisive >= 4

@@ -136,3 +136,55 @@ def test_e2e_480p_short(ref_net):
         assert d.mean() < 2e-4 and d.max() < 5e-2, (d.mean(), d.max())
     m = core.memory
     assert [m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size] == list(g['sizes'][-1])
+
+
+def _selector_cases():
+    import ast as _ast
+    g = load_golden('selector')
+    for name in [str(n) for n in g['names']]:
+        masks = [T(m) for m in g[f'{name}/masks']]
+        yield name, T(g[f'{name}/keys']), T(g[f'{name}/shr']), T(g[f'{name}/sel']), masks, _ast.literal_eval(str(g[f'{name}/kwargs'])), \
+            [int(v) for v in g[f'{name}/chosen']], g[f'{name}/oracle_scores']
+
+
+def test_selector_oracle_reproduces_the_reference_recorded_choices():
+    """tests/golden/selector.npz: choices recorded from the IMPORTED reference function (frame_selection.py:99-244, behind
+    arithmetic-free import placeholders, masks at key resolution - tests/golden/make_selector_goldens.py).  The oracle's restatement
+    must make the same choices, with the recorded score trace."""
+    n = 0
+    for name, keys, shr, sel, masks, kw, chosen, scores in _selector_cases():
+        got = R.select_next_candidates(keys, shr, sel, masks, **kw)
+        assert list(got) == chosen, name
+        np.testing.assert_allclose(np.stack(R.select_next_candidates.last_scores), scores, rtol=1e-5, atol=1e-7, err_msg=name)
+        n += 1
+    assert n == 6
+
+
+def test_autocast_restatement_types_and_size_of_its_deviation(synth_sd):
+    """oracle.cpu_ref.RefNetAutocast (CUDA autocast's operator policy restated; PARITY UNPINNED): the dtype each output has under
+    the policy (fp16 convolution outputs, fp32 shrinkage - `pow` is an fp32 operator -, fp32 GRU state, fp32 probabilities) and
+    a deviation from the fp32 network of the size eleven mantissa bits give."""
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    n32, n16 = R.RefNet(synth_sd), R.RefNetAutocast(synth_sd)
+    fr, mk = T(synthetic_frames(1, 96, 128)), T(synthetic_masks(1, 2, 96, 128))
+    a, b = n32.encode_key(fr), n16.encode_key(fr)
+    want = [torch.float16, torch.float32, torch.float16, torch.float16, torch.float16, torch.float16]
+    for x, y, dt, nm in zip(a, b, want, 'key shrinkage selection f16 f8 f4'.split()):
+        assert y.dtype == dt, nm
+        rel = float((x - y.float()).abs().max() / x.abs().max())
+        assert 1e-5 < rel < 1e-2, (nm, rel)
+    h = torch.zeros(1, 2, 64, 6, 8)
+    va, vb = n32.encode_value(fr, a[3], h, mk), n16.encode_value(fr, b[3], h, mk)
+    assert vb[0].dtype == torch.float16 and vb[1].dtype == torch.float32
+    ro = torch.randn(1, 2, 512, 6, 8, generator=torch.Generator().manual_seed(3)) * 0.1
+    sa, sb = n32.segment(a[3:], ro, va[1]), n16.segment(b[3:], ro.half(), vb[1])
+    assert sb[0].dtype == torch.float32 and sb[2].dtype == torch.float32
+    assert float((sa[2] - sb[2]).abs().max()) < 5e-2 and float((sa[0] - sb[0]).abs().max()) < 1e-2
+    # the memory's GEMMs under the policy: fp16 results of a_sq / two_ab -> similarity errors of the size of an fp16 ulp of |a_sq|
+    g = torch.Generator().manual_seed(5)
+    mkk, ms = torch.randn(1, 64, 300, generator=g) * 0.5, 1 + torch.rand(1, 1, 300, generator=g)
+    qk, qe = torch.randn(1, 64, 40, generator=g) * 0.5, torch.rand(1, 64, 40, generator=g)
+    s32, s16 = R.get_similarity(mkk, ms, qk, qe), R.get_similarity_autocast(mkk, ms, qk.half(), qe.half())
+    assert s16.dtype == torch.float32
+    err = float((s32 - s16).abs().max())
+    assert 1e-4 < err < 5e-2, err
