@@ -76,8 +76,9 @@ WORKLOADS = {
     'b32motion': dict(H=480, W=854, K=1, perm=32, mem_every=10 ** 9, count_usage=False, n_query=32, motion=6, cut_every=16,
                       desc='B32-motion: as B32, but the query frames move 6 px per frame and every 16th frame is a hard scene cut '
                            '(mirrored, shifted scene): loose hint bounds, overflowing candidate lists, second filter pass'),
-    'c3': dict(H=480, W=854, K=3, perm=1, mem_every=5, count_usage=True, n_query=32,
-               desc='C3 stream: 480x854, 3 objects, 1 permanent frame, mem_every=5, long-term consolidation'),
+    'c3': dict(H=480, W=854, K=3, perm=1, mem_every=5, count_usage=True, n_query=32, conditioning='multi_object',
+               desc='C3 stream: 480x854, 3 objects, 1 permanent frame, mem_every=5, long-term consolidation; multi-object conditioning of the '
+                    'synthetic checkpoint (xmem2_amd.synth: without it 45 % of the pixels are ties between objects)'),
     'c4': dict(H=720, W=1280, K=1, perm=256, mem_every=10, count_usage=True, n_query=16,
                desc='C4: 720x1280, 1 object, 256 permanent frames (N=921600) + long-term on, mem_every=10'),
     'c5': dict(H=1080, W=1920, K=5, perm=512, mem_every=10 ** 9, count_usage=False, n_query=16,
@@ -173,7 +174,7 @@ def run_gpu(args, device, rank, world):
     from xmem2_amd.synth import synthetic_state_dict
     wl = WORKLOADS[args.workload]
     cfg = workload_config(wl)
-    sd = synthetic_state_dict(0)
+    sd = synthetic_state_dict(0, conditioning=wl.get('conditioning'))
     net = XMem(dict(cfg, precision=args.precision), None).to(device).eval()
     net.load_weights(sd)
     frames, masks, base, n_query = make_clip(wl)
@@ -548,7 +549,7 @@ def run_cpu_baseline(res, args, device):
     gpu.cancel_prefetch()
     del dev
     ious, mism, perr, clear_mism, near_tie, tight_mism = [], 0, 0.0, 0, 0, 0
-    cpu_masks, cpu_probs = [], []
+    cpu_masks, cpu_probs, cpu_margins = [], [], []
     pos = [0]
 
     def cpu_frames(n):
@@ -568,6 +569,7 @@ def run_cpu_baseline(res, args, device):
             perr = max(perr, float((pg - p[:, 4::8, 4::8]).abs().max()))
             top2 = torch.topk(p, 2, dim=0).values                       # the CPU path's own top-2 margin per pixel
             margin = (top2[0] - top2[1]).numpy()
+            cpu_margins.append(margin.astype(np.float32))
             diff = (g != np.asarray(m))
             clear_mism += int((diff & (margin > CLEAR_MARGIN)).sum())
             tight_mism += int((diff & (margin > TIGHT_MARGIN)).sum())
@@ -599,7 +601,10 @@ def run_cpu_baseline(res, args, device):
             two.append(np.asarray(R.post_process(p2)))
             perr2 = max(perr2, float((cpu_probs[i] - p2[:, 4::8, 4::8]).abs().max()))
         A, B = np.stack(cpu_masks), np.stack(two)
+        M = np.stack(cpu_margins)
         floor = dict(frames=len(two), second_run_threads=t2,
+                     argmax_mismatch_pixels_at_clear_cpu_margin=int(((A != B) & (M > CLEAR_MARGIN)).sum()),
+                     argmax_mismatch_pixels_at_survey_margin=int(((A != B) & (M > TIGHT_MARGIN)).sum()),
                      first_run_threads=f'sweep {sweep} over the first {sum(w + k for _, w, k in plan)} frames, then {best_t}',
                      argmax_mismatch_pixels=int((A != B).sum()), pixels=int(A.size),
                      mask_iou_min=float(min(R.compute_array_iou(a, b) for a, b in zip(cpu_masks, two))),

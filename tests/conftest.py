@@ -49,6 +49,28 @@ def synth_sd():
 
 
 @pytest.fixture(scope='session')
+def synth_sd_mo():
+    """The multi-object conditioning of the synthetic checkpoint (xmem2_amd.synth, conditioning='multi_object'): the object-specific path
+    dominates the shared image features, so that several objects do not saturate on the same pixels (config-3 clips)."""
+    from xmem2_amd.synth import synthetic_state_dict
+    return synthetic_state_dict(0, conditioning='multi_object')
+
+
+@pytest.fixture(scope='session')
+def hip_net_mo(synth_sd_mo):
+    from xmem2_amd.network import XMem
+    net = XMem({'key_dim': 64, 'value_dim': 512, 'hidden_dim': 64, 'precision': 'fp32'}, None).to('cuda').eval()
+    net.load_weights(synth_sd_mo)
+    return net
+
+
+@pytest.fixture(scope='session')
+def ref_net_mo(synth_sd_mo):
+    from oracle import cpu_ref
+    return cpu_ref.RefNet(synth_sd_mo)
+
+
+@pytest.fixture(scope='session')
 def device():
     return torch.device('cuda', 0)
 

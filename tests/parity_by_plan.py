@@ -24,14 +24,15 @@ from xmem2_amd.synth import synthetic_state_dict  # noqa: E402
 
 
 def main():
-    sd = synthetic_state_dict(0)
-    ref_net = cpu_ref.RefNet(sd)
+    sds = {None: synthetic_state_dict(0), 'multi_object': synthetic_state_dict(0, conditioning='multi_object')}
     clips = [U.c3_clip(), U.golden_clip('240p_2obj', (240, 427), 2)]
     if len(sys.argv) > 1:                                        # e.g. `parity_by_plan.py 240p_2obj`: only the named clips
         clips = [c for c in clips if c.name in sys.argv[1:]]
     print(f'device {torch.cuda.get_device_name(0)}; oracle threads: 1 (the goldens\' count) and 8; host cores {os.cpu_count()}')
     for clip in clips:
         t0 = time.time()
+        sd = sds[U.C3_CONDITIONING if clip.name.startswith('480p_3obj') else None]       # the config-3 clip runs on the multi-object conditioning
+        ref_net = cpu_ref.RefNet(sd)
         o1, _, s1 = U.run_oracle(ref_net, clip, 1)
         o8, _, _ = U.run_oracle(ref_net, clip, 8)
         first_lt = next((i for i, z in enumerate(s1) if z[2] > 0), None)

@@ -25,8 +25,8 @@ T = torch.from_numpy
 
 def _cfg():
     from conftest import base_config
-    # memory frames at steps 2, 4, 6; the third fills the temporary store (T_max = 3) -> compress_features:
-    # 2 frames of candidates -> 128 prototypes, 1 frame stays
+    # memory frames at steps 2, 4, 6, 8; the third fills the temporary store (T_max = 3) -> compress_features at step 6:
+    # 2 frames of candidates -> 128 prototypes, 1 frame stays; three more hinted frames follow
     return base_config(mem_every=2, max_mid_term_frames=3, min_mid_term_frames=1, num_prototypes=128)
 
 
@@ -71,7 +71,7 @@ def _run_stream(hip_net, frames, masks, P, base, steps, hinted, check=None):
 def test_c4_stream_720p_256_permanent_frames_with_consolidation(hip_net, ref_net):
     from xmem2_amd import ops
     from xmem2_amd.synth import synthetic_frames, synthetic_masks
-    hw, P, base, steps, top_k = (720, 1280), 256, 8, 8, 30
+    hw, P, base, steps, top_k = (720, 1280), 256, 8, 10, 30
     n_hw = (720 // 16) * (1280 // 16)
     frames = T(synthetic_frames(base + steps, *hw)).cuda()
     masks = T(synthetic_masks(base + steps, 1, *hw)).cuda()

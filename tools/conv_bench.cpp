@@ -52,8 +52,9 @@ int main(int argc, char** argv) {
     }
     if (jobs.empty()) { fprintf(stderr, "usage: conv_bench [-n iters] [-r relu_in,res,relu_out] \"B H W Cin Cout\" plan[,plan] ...\n"); return 1; }
     static const double G2[12] = {1, 0, 0, 0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 0, 0, 1};
-    static const double G4[18] = {0.25, 0, 0, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6,
-                                  1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 24, -1.0 / 12, 1.0 / 6, 0, 0, 1};
+    // F(4x4) with the points {0, +-3/4, +-3/2, inf} (csrc/conv_mfma.hip): rows (1, p, p^2) / N_p, N_p = prod (p - p_k)
+    static const double G4[18] = {64.0 / 81, 0, 0, -128.0 / 243, -32.0 / 81, -8.0 / 27, -128.0 / 243, 32.0 / 81, -8.0 / 27,
+                                  32.0 / 243, 16.0 / 81, 8.0 / 27, 32.0 / 243, -16.0 / 81, 8.0 / 27, 0, 0, 1};
     if (xmem_version() != XMEM_ABI_VERSION) { fprintf(stderr, "libxmem_hip.so has ABI version %d, this driver was built for %d: rebuild tools/conv_bench\n", xmem_version(), XMEM_ABI_VERSION); return 2; }
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

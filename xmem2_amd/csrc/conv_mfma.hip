@@ -222,6 +222,19 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
     // whole one after the last MFMA (the same lane / row mapping as the epilogue below).
     constexpr bool EARLY_RES = TM * TN <= 2;
     float rve[EARLY_RES ? TM * TN : 1][16];
+    // Two-accumulator tiles (128x64) also request the per-channel scale / shift of the epilogue here (round 5): -5 ... -12 % on the
+    // batch-4 pointwise layers that take that tile; the 64x64 tile does not gain (+-2 %) and keeps the epilogue fetch
+    // (profiles/r05_pointwise_prefetch_ab.txt).
+    constexpr bool EARLY_SS = TM * TN == 2;
+    float sce[EARLY_SS ? TN : 1], she[EARLY_SS ? TN : 1];
+    if (EARLY_SS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n0 + wn * 32 * TN + j * 32 + l31, p.Cout - 1);
+            sce[j] = mode >= 2 ? p.scale[n] : 1.f;
+            she[j] = mode >= 2 ? p.shift[n] : 0.f;
+        }
+    }
     if (EARLY_RES && mode == 3) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -316,7 +329,8 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
         const int n = n0 + wn * 32 * TN + j * 32 + l31;
         if (n >= p.Cout) continue;
         float sc = 1.f, sh = 0.f;
-        if (mode >= 2) { sc = p.scale[n]; sh = p.shift[n]; }
+        if (EARLY_SS) { sc = sce[j]; sh = she[j]; }
+        else if (mode >= 2) { sc = p.scale[n]; sh = p.shift[n]; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * 32 * TM + i * 32 + 4 * lh;          // this lane's rows: mb + (r & 3) + 8 * (r >> 2)
@@ -676,26 +690,45 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(WinoArgs p) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// Winograd F(4x4, 3x3) for the LARGE 3x3 / stride 1 layers (plan_tile 17..22): 36 multiplies per 4x4 outputs instead of
+// Winograd F(4x4, 3x3) for the LARGE 3x3 / stride 1 layers (plan_tile 17..28): 36 multiplies per 4x4 outputs instead of
 // 144 - 4x fewer MFMA FLOPs than the direct form (F(2x2): 2.25x) and 2.25 / 4 of F(2x2)'s transform-domain traffic
-// (36 values per 16 outputs instead of 16 per 4).  Interpolation points {0, +-1, +-2, inf}; all fp32; measured error vs a
-// fp64 convolution 9e-6 of the output scale (F(2x2): 5e-7, direct: 2e-7) - inside the 2e-4 parity tolerance, which is why
-// it is used only where it pays (>= 1/8 resolution) and F(2x2) elsewhere.
+// (36 values per 16 outputs instead of 16 per 4).  All fp32.
 //   V = B^T d B (6x6 input tile, stride 4), M_xi = V_xi U_xi^T on the same MFMA GEMM (36 groups), Y = A^T M A (4x4).
+// INTERPOLATION POINTS {0, +-3/4, +-3/2, inf} (round 5; rounds 2-4: the textbook {0, +-1, +-2, inf}).  The error of a Winograd
+// convolution is set by the magnitudes in A, B, G, i.e. by the points (Barabasz et al., "Error analysis and improving the accuracy
+// of Winograd convolution for DNNs", 2018): with +-1, +-2 the output transform multiplies by up to 8 and the input transform by up to
+// 5; with +-3/4, +-3/2 every coefficient of A^T is <= 3.375 and of B^T <= 2.8125.  Simulated in fp32 against an fp64 convolution
+// (relu'd normal inputs, Cin 64 / 512 / 1600): max error / max |y| 2.5e-6 / 5.0e-6 / 8.6e-6 -> 7.4e-7 / 1.4e-6 / 2.3e-6 (3.4-3.7x
+// lower, rms 2x lower) - the level of F(2x2) and of the direct form's own fp32 summation.  It matters: on the 3-object 480p clip
+// (multi-object conditioning) the textbook points cost 73 argmax pixels against the oracle where the reference disagrees with
+// itself on 20 and F(2x2) on 1 (profiles/r05_c3_parity_by_plan.txt).  All powers of 3/4 and 3/2 are exact in fp32, so B^T and A^T
+// below are exact constants; the non-dyadic factors (1 / N_i) live in G, applied once at load time in fp64 (ops.winograd4_weights).
+// Rows of B^T = coefficients of the monic polynomials prod_{k != i} (x - p_k); rows of A^T = powers of the points:
+//   p = (0, a, -a, b, -b, inf), a = 3/4, b = 3/2
 // ----------------------------------------------------------------------------------------------
+#define W4_A 0.75f
+#define W4_B 1.5f
+#define W4_A2 0.5625f          // a^2
+#define W4_B2 2.25f            // b^2
+#define W4_A3 0.421875f        // a^3
+#define W4_B3 3.375f           // b^3
+#define W4_A2B2 1.265625f      // a^2 b^2
+#define W4_SUM 2.8125f         // a^2 + b^2
+#define W4_AB2 1.6875f         // a b^2
+#define W4_BA2 0.84375f        // b a^2
 __device__ __forceinline__ void wino4_bt(const f32x4* d, f32x4* t) {      // t = B^T d for one 6-vector
-    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-    t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
-    t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
-    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    t[0] = W4_A2B2 * d[0] - W4_SUM * d[2] + d[4];
+    t[1] = -W4_AB2 * d[1] - W4_B2 * d[2] + W4_A * d[3] + d[4];
+    t[2] = W4_AB2 * d[1] - W4_B2 * d[2] - W4_A * d[3] + d[4];
+    t[3] = -W4_BA2 * d[1] - W4_A2 * d[2] + W4_B * d[3] + d[4];
+    t[4] = W4_BA2 * d[1] - W4_A2 * d[2] - W4_B * d[3] + d[4];
+    t[5] = W4_A2B2 * d[1] - W4_SUM * d[3] + d[5];
 }
 __device__ __forceinline__ void wino4_at(const f32x4* m, f32x4* s) {      // s = A^T m for one 6-vector
     s[0] = m[0] + m[1] + m[2] + m[3] + m[4];
-    s[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
-    s[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
-    s[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+    s[1] = W4_A * m[1] - W4_A * m[2] + W4_B * m[3] - W4_B * m[4];
+    s[2] = W4_A2 * m[1] + W4_A2 * m[2] + W4_B2 * m[3] + W4_B2 * m[4];
+    s[3] = W4_A3 * m[1] - W4_A3 * m[2] + W4_B3 * m[3] - W4_B3 * m[4] + m[5];
 }
 
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ in, int ldin, int B, int H, int W, int C, int th, int tw,

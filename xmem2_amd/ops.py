@@ -247,8 +247,18 @@ def split_pack(w, shift=0):
 _WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
 
 
-_WINO4_G = torch.tensor([[0.25, 0.0, 0.0], [-1.0 / 6, -1.0 / 6, -1.0 / 6], [-1.0 / 6, 1.0 / 6, -1.0 / 6],
-                         [1.0 / 24, 1.0 / 12, 1.0 / 6], [1.0 / 24, -1.0 / 12, 1.0 / 6], [0.0, 0.0, 1.0]], dtype=torch.float64)
+# F(4x4,3x3) with the interpolation points {0, +-3/4, +-3/2, inf} (csrc/conv_mfma.hip: why, and what the transforms look like).
+# Row i of G = (1, p_i, p_i^2) / N_i with N_i = prod_{k != i} (p_i - p_k) over the finite points; the row of infinity is (0, 0, 1).
+def _wino4_g(a=0.75, b=1.5):
+    from fractions import Fraction as Fr
+    a, b = Fr(a), Fr(b)
+    na, nb = 2 * a * a * (a * a - b * b), 2 * b * b * (b * b - a * a)
+    rows = [[1 / (a * a * b * b), 0, 0], [1 / na, a / na, a * a / na], [1 / na, -a / na, a * a / na],
+            [1 / nb, b / nb, b * b / nb], [1 / nb, -b / nb, b * b / nb], [0, 0, 1]]
+    return torch.tensor([[float(v) for v in r] for r in rows], dtype=torch.float64)       # exact rationals rounded once to fp64
+
+
+_WINO4_G = _wino4_g()
 
 
 def winograd4_weights(w):

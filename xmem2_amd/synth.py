@@ -47,7 +47,7 @@ def hash_uniform(n, stream, lo=0.0, hi=1.0):
     return (lo + (hi - lo) * _uniform(n, stream * 4 + 7000001)).astype(np.float32)
 
 
-def synthetic_state_dict(seed=0, key_dim=64, value_dim=512, hidden_dim=64, as_torch=True):
+def synthetic_state_dict(seed=0, key_dim=64, value_dim=512, hidden_dim=64, as_torch=True, conditioning=None):
     """Conditioned synthetic checkpoint with the reference's tensor names.
 
     Convolutions: He-normal (as model/resnet.py:132-135) ; BatchNorm: non-trivial
@@ -55,7 +55,17 @@ def synthetic_state_dict(seed=0, key_dim=64, value_dim=512, hidden_dim=64, as_to
     the last BN of every residual branch is damped (x0.35) so activations do not
     explode through the 13 bottlenecks; key / shrinkage / selection projections are
     scaled down so that similarities stay in exp()'s non-underflowing range.
+
+    conditioning='multi_object' (the K >= 2 benchmark / parity clips, round 5): with the plain conditioning every object's logit
+    map follows the SHARED image features (skip connections, the f16 half of the decoder's fuser), so several objects saturate on
+    the same pixels and 45 % of a 3-object frame's pixels are exact or near ties between two objects - a clip on which the
+    reference's own argmax is noise.  This variant makes the object-specific path dominate: the value encoder's mask / other-mask
+    input channels x8 / x-8, the decoder fuser's f16 half x0.1, the decoder's skip convolutions x0.3 (applied to the SAME hash
+    values, so it is as reproducible as the base checkpoint).  Measured on the config-3 clip (480p, 3 objects, consolidation):
+    pixels within 0.01 of a tie 45 % -> 1 %, the reference's 8-vs-1-thread IoU 0.9977-0.9993 -> 0.9992-0.9995.
     """
+    if conditioning not in (None, 'multi_object'):
+        raise ValueError(f'unknown conditioning {conditioning!r}')
     spec = state_dict_spec(key_dim, value_dim, hidden_dim)
     out = {}
     for ti, (name, shape) in enumerate(spec.items()):
@@ -96,6 +106,16 @@ def synthetic_state_dict(seed=0, key_dim=64, value_dim=512, hidden_dim=64, as_to
             elif name == 'decoder.pred.weight':
                 arr = arr * np.float32(18.0)
         arr = np.asarray(arr).reshape(shape)
+        if conditioning == 'multi_object':
+            if name == 'value_encoder.conv1.weight' and shape[1] >= 5:
+                arr = arr.copy()
+                arr[:, 3] *= np.float32(8.0)
+                arr[:, 4] *= np.float32(-8.0)
+            elif name in ('decoder.fuser.block1.conv1.weight', 'decoder.fuser.block1.downsample.weight'):
+                arr = arr.copy()
+                arr[:, :1024] *= np.float32(0.1)
+            elif name in ('decoder.up_16_8.skip_conv.weight', 'decoder.up_8_4.skip_conv.weight'):
+                arr = arr * np.float32(0.3)
         out[name] = arr
     if as_torch:
         import torch
