@@ -11,8 +11,8 @@ step is pinned three ways instead:
   * the usage the step adds to the temporary store equals the affinity mass that landed on it (never on the permanent store);
   * the memory sizes follow, frame by frame, the trajectory of the oracle's RefCore run on the SAME schedule at a small
     resolution (sizes are multiples of HW; the prototype count is absolute).
-Size-independent property on top: the whole stream again WITHOUT hints (the un-hinted fp32 select on every frame) gives
-bit-identical masks."""
+Size-independent properties on top: the whole stream again WITHOUT hints (the un-hinted fp32 select on every frame), and again with
+every readout enqueued a frame ahead on the readout stream (early readout), gives bit-identical masks and memories."""
 import numpy as np
 import pytest
 import torch
@@ -47,12 +47,13 @@ def _oracle_size_trajectory(ref_net, steps):
     return out
 
 
-def _run_stream(hip_net, frames, masks, P, base, steps, hinted, check=None):
+def _run_stream(hip_net, frames, masks, P, base, steps, hinted, check=None, early=False):
     from xmem2_amd.inference_core import InferenceCore
     from xmem2_amd import ops
     core = InferenceCore(hip_net, _cfg())
     core.set_all_labels([1])
     core.memory.use_affinity_hint = hinted
+    core.early_readout = early        # (the per-step check reads "the last affinity call": it needs every readout inside its own step)
     for j in range(P):                                     # 8 base frames shifted by distinct offsets (as bench.py make_clip / run_gpu)
         sh = (3 * (j // base), 5 * (j // base))
         core.put_to_permanent_memory(torch.roll(frames[j % base], sh, (1, 2)), torch.roll(masks[j % base], sh, (1, 2)), ti=j)
@@ -167,5 +168,14 @@ def test_c4_stream_720p_256_permanent_frames_with_consolidation(hip_net, ref_net
     assert diff == 0, f'the hinted stream differs from the un-hinted stream on {diff} pixels'
     m1, m2 = core.memory, core2.memory
     assert (m1.temporary_work_mem.size, m1.long_mem.size) == (m2.temporary_work_mem.size, m2.long_mem.size)
+    # ... and with every readout enqueued a frame ahead, under the previous frame's decoder (InferenceCore early readout): same
+    # kernels on the same operands, usage applied when the frame is stepped -> the same masks, memory and usage bit for bit
+    early_masks, core3 = _run_stream(hip_net, frames, masks, P, base, steps, True, early=True)
+    diff = sum(int((a != b).sum()) for a, b in zip(hinted_masks, early_masks))
+    assert diff == 0, f'the early-readout stream differs from the in-step stream on {diff} pixels'
+    m3 = core3.memory
+    assert (m1.temporary_work_mem.size, m1.long_mem.size) == (m3.temporary_work_mem.size, m3.long_mem.size)
+    assert torch.equal(m1.temporary_work_mem.use_count, m3.temporary_work_mem.use_count)
+    assert torch.equal(m1.long_mem.key_rows(), m3.long_mem.key_rows())
     print(f'C4 stream: {steps} steps, N up to {P * n_hw + 3 * n_hw}; sampled queries with the oracle\'s exact index set '
           f'{stats["same_sets"]}/{stats["sampled"]}; sizes {[t for t in traj]}; object fraction {obj:.3f}')

@@ -164,8 +164,10 @@ def test_streaming_gemm_pointwise_plans(case):
 
 
 def test_winograd_f4_accuracy_at_a_large_layer():
-    """F(4x4,3x3) is what the large 3x3 layers run by default: its error against a fp64 convolution stays ~1e-5 of the
-    output scale (F(2x2): ~5e-7), 20x inside the parity tolerance; odd sizes exercise the partial border tiles."""
+    """F(4x4,3x3) is what the large 3x3 layers run by default.  With the interpolation points {0, +-3/4, +-3/2, inf} (round 5; the
+    textbook +-1, +-2 gave ~1e-5) its error against a fp64 convolution is a few 1e-6 of the output scale - the class of F(2x2) and of
+    the direct form's own fp32 summation - and gated there: the 3-object parity clip showed that 1e-5 is NOT harmless
+    (profiles/r05_c3_parity_by_plan.txt).  Odd sizes exercise the partial border tiles."""
     from xmem2_amd import ops
     from xmem2_amd.ops import ConvWeights
     gen = g_(5)
@@ -180,7 +182,7 @@ def test_winograd_f4_accuracy_at_a_large_layer():
             out = nchw(ops.conv2d(nhwc(x), cw, plan=plan)).double()
             errs[name] = float((out - ref).abs().max()) / scale
         print(f'{(B, H, W, Cin, Cout)}: max err / scale {errs}')
-        assert errs['direct'] < 2e-6 and errs['F2'] < 5e-6 and errs['F4'] < 5e-5 and errs['default'] < 5e-5
+        assert errs['direct'] < 2e-6 and errs['F2'] < 5e-6 and errs['F4'] < 8e-6 and errs['default'] < 8e-6
 
 
 def test_conv2d_into_channel_slice_and_strided_input():

@@ -144,3 +144,53 @@ def test_clear_memory_keep_permanent_vs_oracle(hip_net, ref_net, n_obj):
     assert ref.put_to_permanent_memory(frames[3], masks[3], ti=5) is True
     core.clear_memory(); ref.clear_memory()
     assert core.memory.permanent_work_mem.size == ref.memory.permanent_work_mem.size == 0
+
+
+@pytest.mark.parametrize('n_obj', [1, 2])
+def test_early_readout_is_only_a_schedule(hip_net, n_obj):
+    """InferenceCore early readout: the memory readout of the next prefetched frame runs on a third stream under the current frame's
+    decoder.  It must change nothing but the schedule: probabilities, memory contents, usage counters and hidden state bit-identical
+    to the in-step order - across memory frames (the next readout must see the inserted frame), a consolidation, a batch boundary
+    without hints, a step whose flags differ from the prediction (end=True) and a permanent-memory edit between two steps (the
+    readout enqueued ahead read the OLD memory and must be discarded)."""
+    from conftest import base_config
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    hw, t = (240, 432), 16
+    cfg = base_config(mem_every=3, max_mid_term_frames=3, min_mid_term_frames=1, num_prototypes=32)
+    frames = T(synthetic_frames(t, *hw)).cuda(); masks = T(synthetic_masks(t, n_obj, *hw)).cuda()
+    labels = list(range(1, n_obj + 1))
+
+    def run(early):
+        core = InferenceCore(hip_net, cfg)
+        core.early_readout = early
+        core.set_all_labels(labels)
+        core.put_to_permanent_memory(frames[0], masks[0], ti=0)
+        probs, taken = [], 0
+        for i in range(1, t):
+            if (i - 1) % 4 == 0:
+                core.prefetch_keys(list(frames[i:i + 4]))
+            if i == 10:                                        # an edit between two steps: the readout enqueued ahead is stale
+                assert (core._early is not None) == early
+                core.put_to_permanent_memory(frames[1], masks[1], ti=1)
+                assert core._early is None
+                core.prefetch_keys(list(frames[i:13]))         # (the edit dropped the pending hints: hint the rest of the batch again)
+            had = core._early is not None
+            p = core.step(frames[i], None, None, end=(i == t - 1))
+            taken += int(had)
+            probs.append(p.clone())
+        m = core.memory
+        state = (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size,
+                 m.temporary_work_mem.use_count.clone() if m.temporary_work_mem.size else None,
+                 m.long_mem.key_rows().clone() if m.long_mem.size else None, m.get_hidden().clone())
+        return probs, state, taken
+
+    p0, s0, n0 = run(False)
+    p1, s1, n1 = run(True)
+    assert n0 == 0 and n1 >= 6, (n0, n1)                       # the early path really ran
+    assert s0[2] > 0, 'the clip must contain a consolidation'
+    for i, (a, b) in enumerate(zip(p0, p1)):
+        assert torch.equal(a, b), f'frame {i + 1}: probabilities differ (max {float((a - b).abs().max()):.2e})'
+    assert s0[:3] == s1[:3]
+    for a, b in zip(s0[3:], s1[3:]):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))

@@ -6,6 +6,7 @@ reference's conventions (image ``3 x H x W`` float32 normalised, mask ``K x H x 
 """
 import collections
 import functools
+import os
 import weakref
 
 import torch
@@ -41,6 +42,12 @@ class InferenceCore:
         self._pfq = collections.deque()      # prefetched frames in the order step() will consume them
         self._group_free = {}                # buffer group -> event after which the side stream may overwrite it
         self._group_parity = {}
+        # early readout: the memory readout of the NEXT prefetched frame (it needs that frame's key and the memory, not this frame's
+        # decoder) is enqueued on a third stream as soon as this frame's own readout / memory insertion is done, and runs under this
+        # frame's decoder.  Same kernels on the same operands; consumed by the next step() only if the memory is unchanged.
+        self._ro_stream = None
+        self._early = None
+        self.early_readout = os.environ.get('XMEM_EARLY_READOUT', '1') != '0'
         # owner token of this core's captured decoder stages (they update ITS hidden state in place); recycled when the core dies
         if hasattr(network, 'acquire_owner'):
             self._uid = network.acquire_owner()
@@ -65,6 +72,7 @@ class InferenceCore:
         self.last_mem_ti = 0
         if not self.deep_update_sync:
             self.last_deep_update_ti = -self.deep_update_every
+        self._retire_early()                          # a readout enqueued ahead reads the stores that are about to go
         self.memory = self.memory.copy_perm_mem_only() if keep_permanent else MemoryManager(config=self.config)
 
     def update_config(self, config):
@@ -223,14 +231,25 @@ class InferenceCore:
             self.curr_ti -= 1
 
         prob = prob_padded = None
+        ro_done = None
         if need_segment:
             hidden = mem.get_hidden()
             K = hidden.shape[0]
             cat16 = net.new_decoder_input(K, h, w, f16.device, slot=slot, owner=self._uid, h_out=is_normal_update,
                                           has_skips=skips is not None)
             ld = cat16.shape[3]
-            mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024,
-                                  disable_usage_updates=disable_memory_updates)
+            early = self._take_early(pf, mem, K, cat16)
+            if early is not None:
+                # this frame's readout ran ahead, under the previous frame's decoder: only its usage updates are still due
+                if early['cat16'].data_ptr() != cat16.data_ptr():        # another decoder variant than predicted (last frame, ...)
+                    ops.copy_channels(early['cat16'], cat16, 1024, c=net.value_dim, src_off=1024)
+                if not disable_memory_updates:
+                    mem.apply_usage(early['pending'])
+            else:
+                mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024,
+                                      disable_usage_updates=disable_memory_updates)
+            ro_done = torch.cuda.Event()
+            ro_done.record()
             new_hidden, prob, prob_padded = net.segment_nhwc(f16, f8, f4, cat16, hidden, hw, (self.pad[2], self.pad[0]),
                                                              h_out=is_normal_update, skips=skips, slot=slot, owner=self._uid)
             if is_normal_update:
@@ -269,16 +288,76 @@ class InferenceCore:
             done = torch.cuda.Event()
             done.record()
             self._group_free[pf['gid']] = done        # latest main-stream reader of that group's key-encoder buffers
+        if self.early_readout and need_segment and self._pfq and mask is None and not end:
+            # (a memory frame's value encoder and insertion are enqueued by now: the next readout must see them)
+            self._enqueue_early_readout(ro_done if (ro_done is not None and not is_mem_frame) else None)
         if return_key_and_stuff:
             views = self._key_views(key, shrinkage, selection, h, w)
             return (prob,) + tuple(v.clone() if v is not None else None for v in views)   # caller-owned copies
         return prob
+
+    # ---- early readout -----------------------------------------------------------------------------
+    def _enqueue_early_readout(self, after):
+        """match_memory of the next prefetched frame on the readout stream.  `after`: main-stream event the readout depends on
+        (this frame's readout: the hint, the usage order) - None = everything enqueued on the main stream so far."""
+        net, mem = self.network, self.memory
+        nxt = self._pfq[0]
+        hidden = mem.get_hidden()
+        if hidden is None or not (getattr(net, 'use_graphs', False) and net.device.type == 'cuda') or ops.eager_only():
+            return
+        key, _, selection, f16 = nxt['outs'][0], nxt['outs'][1], nxt['outs'][2], nxt['outs'][3]
+        h, w, K = f16.shape[1], f16.shape[2], hidden.shape[0]
+        main = torch.cuda.current_stream()
+        if self._ro_stream is None:
+            self._ro_stream = torch.cuda.Stream(device=net.device)
+        if after is None:
+            after = torch.cuda.Event()
+            after.record(main)
+        R = self._ro_stream
+        R.wait_event(nxt['event'])                    # the side stream finished that frame's key encoder
+        R.wait_event(after)
+        # the decoder variant the next step() will most likely run (no mask, not the last frame): its static input buffer
+        nxt_mem = (self.curr_ti + 1 - self.last_mem_ti >= self.mem_every)
+        nxt_deep = (self.deep_update_sync and nxt_mem) or \
+                   (not self.deep_update_sync and self.curr_ti + 1 - self.last_deep_update_ti >= self.deep_update_every)
+        h_out = (not self.deep_update_sync) or (not nxt_deep)
+        pending = []
+        with torch.cuda.stream(R), ops.ws_scope(f'@early#{self._uid}#'):
+            cat16 = net.new_decoder_input(K, h, w, f16.device, slot=nxt['slot'], owner=self._uid, h_out=h_out,
+                                          has_skips=len(nxt['outs']) > 6 and nxt['outs'][6] is not None)
+            ld = cat16.shape[3]
+            mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024, defer_usage=pending)
+            done = torch.cuda.Event()
+            done.record(R)
+        self._early = dict(pf=nxt, mem=mem, version=mem.version, K=K, cat16=cat16, pending=pending, done=done)
+
+    def _take_early(self, pf, mem, K, cat16):
+        """The readout enqueued ahead for this frame, or None (none was, or the frame / memory / object count is not what it read).
+        Either way the main stream first waits for it: it uses scratch and buffers the main stream is about to touch."""
+        e, self._early = self._early, None
+        if e is None:
+            return None
+        main = torch.cuda.current_stream()
+        main.wait_event(e['done'])
+        ok = pf is not None and e['pf'] is pf and e['mem'] is mem and e['version'] == mem.version and e['K'] == K \
+            and tuple(e['cat16'].shape) == tuple(cat16.shape) and e['cat16'].dtype == cat16.dtype
+        for _, w_, idx_, _ in e['pending']:
+            w_.record_stream(main); idx_.record_stream(main)
+        e['cat16'].record_stream(main)
+        return e if ok else None
+
+    def _retire_early(self):
+        e = getattr(self, '_early', None)
+        if e is not None:
+            torch.cuda.current_stream().wait_event(e['done'])
+            self._early = None
 
     def cancel_prefetch(self):
         """Forget pending `prefetch_keys` hints (the next `step()` runs its own key encoder)."""
         self._drop_prefetch()
 
     def _drop_prefetch(self):
+        self._retire_early()
         while self._pfq:
             e = self._pfq.popleft()
             torch.cuda.current_stream().wait_event(e['event'])

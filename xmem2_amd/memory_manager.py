@@ -47,6 +47,9 @@ class MemoryManager:
         # call as a bound hint (XMEM_AFFINITY_HINT=0 disables; outputs are identical either way)
         self._aff_hint = {}
         self.use_affinity_hint = os.environ.get('XMEM_AFFINITY_HINT', '1') != '0'
+        # bumped by everything that changes what a readout sees (elements added / replaced / removed / consolidated, top_k): a readout
+        # enqueued ahead of its frame (InferenceCore: early readout) is only consumed if the memory still has the version it read
+        self.version = 0
 
     def _read_lt(self, config):
         self.max_mt_frames = config['max_mid_term_frames']
@@ -57,6 +60,7 @@ class MemoryManager:
     def update_config(self, config):
         """memory_manager.py:42-55."""
         self.reset_config = True
+        self.version += 1
         self.hidden_dim = config['hidden_dim']
         self.top_k = config['top_k']
         assert self.enable_long_term == config['enable_long_term'], 'cannot update this'
@@ -66,12 +70,15 @@ class MemoryManager:
             self._read_lt(config)
 
     # ---- readout ---------------------------------------------------------------------------------
-    def match_memory_rows(self, qk, qe, out, out_ld, obj_stride, out_off=0, disable_usage_updates=False):
+    def match_memory_rows(self, qk, qe, out, out_ld, obj_stride, out_off=0, disable_usage_updates=False, defer_usage=None):
         """memory_manager.py:61-190 on row-major operands.
 
         qk / qe: [HW, C_k] (qe may be None).  Writes the readout of object o (objects ordered by group, as the
         reference's torch.cat over groups) to out[o][q][out_off : out_off + C_v] (pixel stride out_ld floats,
-        object stride obj_stride floats).  Returns the number of objects written."""
+        object stride obj_stride floats).  Returns the number of objects written.
+        defer_usage: a list - the usage updates of this readout (memory_manager.py:133-141) are appended to it as
+        (store, w, idx, first) instead of being applied; `apply_usage` applies them later (a readout enqueued ahead of its frame does
+        not know yet whether the frame's step() will ask for disable_memory_updates)."""
         tmp, perm = self.temporary_work_mem, self.permanent_work_mem
         num_groups = max(tmp.num_groups, perm.num_groups)
         use_long = self.enable_long_term and self.long_mem.engaged()
@@ -105,17 +112,27 @@ class MemoryManager:
             if gi == 0 and self.enable_long_term and not disable_usage_updates:
                 # usage from the first group only (it sees every key), memory_manager.py:93-97,133-141,150-155
                 first = 0
+                pending = []
                 if lt is not None:
                     if self.enable_long_term_usage:
-                        lt.update_usage_from(w, idx, 0)          # usage[:, :long_mem_size]
+                        pending.append((lt, w, idx, 0))          # usage[:, :long_mem_size]
                     first = lt.size
-                tmp.update_usage_from(w, idx, first)            # usage[:, long : long + temp]; never permanent
+                pending.append((tmp, w, idx, first))            # usage[:, long : long + temp]; never permanent
+                if defer_usage is not None:
+                    defer_usage.extend(pending)
+                else:
+                    self.apply_usage(pending)
             n_obj = stores[-1].value_rows(gi).shape[0]
             vsegs = [[(st.value_rows(gi)[o] if st is not None else None) for st in stores] for o in range(n_obj)]
             ops.readout_sparse(vsegs, w, idx, self.CV, out, out_ld, obj_stride,
                                out_off=out_off + obj_base * obj_stride)
             obj_base += n_obj
         return obj_base
+
+    @staticmethod
+    def apply_usage(pending):
+        for store, w, idx, first in pending:
+            store.update_usage_from(w, idx, first)
 
     def match_memory(self, query_key, selection, disable_usage_updates=False):
         """Reference-shaped entry: query_key / selection [1,C_k,h,w] -> [K, C_v, h, w] (NHWC-backed view)."""
@@ -133,12 +150,14 @@ class MemoryManager:
     def update_permanent_memory(self, frame_idx, key, shrinkage, value, selection=None):
         """memory_manager.py:192-202."""
         pos = self.frame_id_to_permanent_mem_idx[frame_idx]
+        self.version += 1
         self.permanent_work_mem.replace_at(pos, key, value, shrinkage, selection)
 
     def remove_from_permanent_memory(self, frame_idx):
         """memory_manager.py:204-210.  NOTE (reference quirk, Appendix B): the saved *frame position* is passed
         as an *element offset* and later frames are not renumbered; kept as is for GUI compatibility."""
         pos = self.frame_id_to_permanent_mem_idx[frame_idx]
+        self.version += 1
         self.permanent_work_mem.remove_at(pos, self.HW)
         del self.frame_id_to_permanent_mem_idx[frame_idx]
 
@@ -147,6 +166,7 @@ class MemoryManager:
                    hw_shape=None):
         """memory_manager.py:212-281 with row-major operands: key [HW,C_k], shrinkage [HW], value [K,HW,C_v],
         selection [HW,C_k] | None.  hw_shape = (h, w) of the stride-16 grid."""
+        self.version += 1
         if self.H is None or self.reset_config:
             self.reset_config = False
             if hw_shape is not None:
