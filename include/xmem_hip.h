@@ -39,8 +39,9 @@ typedef enum {
 } xmem_status;
 
 /* ABI version of this header.  2 (round 4): xmem_conv_desc grew (in_half / out_half / w_half), storage-typed `_t` entry points, plan
- * tiles 23..40.  A caller compiled against another version must not pass structs: check xmem_version() == XMEM_ABI_VERSION at load. */
-#define XMEM_ABI_VERSION 2
+ * tiles 23..40.  3 (round 5): no layout change, but the MEANING of w_winograd4 / w_winograd4_split changed - the F(4x4) transforms use the
+ * interpolation points (0, +-3/4, +-3/2, inf), a caller must form G g G^T with the matching G (see xmem_conv_desc.w_winograd4).  A caller compiled against another version must not pass structs: check xmem_version() == XMEM_ABI_VERSION at load. */
+#define XMEM_ABI_VERSION 3
 int xmem_version(void);
 const char* xmem_last_error_string(int code); /* static string for a status code */
 
@@ -80,8 +81,13 @@ typedef struct {
     int res_broadcast;  /* 1: res is ONE image [Ho][Wo][ldres] added to every batch element (the per-object halves of the
                            fuser convolutions share the f16 half, model/modules.py:31-41 on cat([x, g])) */
     const void* w_winograd_f16; /* optional [16][Cout][Cin] IEEE half: the same G g G^T rounded to fp16 (plan_tile 16 only) */
-    const float* w_winograd4;   /* optional [36][Cout][Cin]: G g G^T of Winograd F(4x4,3x3) (plan_tile 17..22 = the GEMM tiles of
-                                   plans 7..12 inside the F(4x4) path; fp32, ~9e-6 of the output scale vs a fp64 convolution) */
+    const float* w_winograd4;   /* optional [36][Cout][Cin]: G g G^T of Winograd F(4x4,3x3) (plan_tile 17..28 = the GEMM tiles of
+                                   plans 7..12 / the streaming GEMM inside the F(4x4) path; fp32).  INTERPOLATION POINTS
+                                   p = (0, 3/4, -3/4, 3/2, -3/2, inf) since ABI version 3 (version 2: 0, +-1, +-2, inf): row i of G is
+                                   (1, p_i, p_i^2) / N_i with N_i = prod_{k != i} (p_i - p_k) over the finite points, the row of
+                                   infinity (0, 0, 1):  64/81 0 0 | -128/243 -32/81 -8/27 | -128/243 32/81 -8/27 | 32/243 16/81 8/27 |
+                                   32/243 -16/81 8/27 | 0 0 1.  Form it in fp64 and round once (xmem2_amd.ops.winograd4_weights).
+                                   Error against a fp64 convolution ~3e-6 of the output scale (the textbook points: ~1e-5). */
     /* SPLIT-OPERAND ARITHMETIC (opt-in mode 'fp32x', never the default): arith = 1 and w_split != NULL run every GEMM of the
      * call on v_mfma_f32_32x32x16_f16 with each fp32 operand carried as two halfs (x = hi + lo, relative representation error
      * <= 2^-21; the four partial products are accumulated in fp32).  The split weights have the SHAPE of their fp32

@@ -200,3 +200,35 @@ def test_split_operand_mode_is_fp32_class(synth_sd):
     print(f'fp32x, 480p clip vs the reference-recorded masks: min IoU {min(ious):.5f}, mismatch {mism:.2e}, mean |dp| {d.mean():.2e}')
     assert min(ious) >= 0.999 and mism < 1e-4 and d.mean() < 5e-4
     assert np.array_equal(probs.argmax(1)[clear], gold['prob_ds8'].argmax(1)[clear])
+
+
+def test_forked_downsample_branch_changes_nothing(synth_sd):
+    """XMem.branch_overlap: inside a captured stage the downsample convolution of a GroupResBlock runs on a forked stream beside conv1
+    (decoder fuser block1, up_16_8.out_conv, value-encoder fuser).  Same kernels on the same operands: decoder and value-encoder
+    outputs of the graph path must be bit-identical with the fork on and off, for one and for two objects."""
+    from xmem2_amd import ops
+    from xmem2_amd.network import XMem
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    outs = {}
+    for fork in (False, True):
+        net = XMem({'key_dim': 64, 'value_dim': 512, 'hidden_dim': 64}, None).to('cuda').eval()
+        net.load_weights(synth_sd)
+        net.branch_overlap = fork
+        res = []
+        for K in (1, 2):
+            fr = torch.from_numpy(synthetic_frames(1, 240, 432)).cuda()
+            mk = torch.from_numpy(synthetic_masks(1, K, 240, 432)).cuda()
+            img4 = ops.pack_image(fr[0], 240, 432, 0, 0)
+            key, shr, sel, f16, f8, f4 = net.encode_key_nhwc(img4, True, True)
+            hidden = (torch.randn(K, 15, 27, 64, generator=torch.Generator().manual_seed(K)) * 0.3).cuda()
+            val, h2 = net.encode_value_nhwc(img4, f16, hidden.clone(), mk[0], True)
+            cat16 = net.new_decoder_input(K, 15, 27, f16.device)
+            ops.copy_channels(val, cat16, 1024)                         # any readout: the value itself
+            for _ in range(2):                                         # first call captures, second replays
+                nh, prob, _ = net.segment_nhwc(f16, f8, f4, cat16, hidden.clone(), (240, 432), (0, 0), h_out=True)
+            res.append((val.clone(), h2.clone(), prob.clone(), nh.clone()))
+        outs[fork] = res
+        assert (net._branch is not None) == fork
+    for a, b in zip(outs[False], outs[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)

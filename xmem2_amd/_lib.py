@@ -16,7 +16,7 @@ c_float_p = C.c_void_p
 c_void_p = C.c_void_p
 
 
-ABI_VERSION = 2          # include/xmem_hip.h XMEM_ABI_VERSION: the layout of ConvDesc below belongs to it
+ABI_VERSION = 3          # include/xmem_hip.h XMEM_ABI_VERSION: the layout of ConvDesc below belongs to it
 
 
 class ConvDesc(C.Structure):

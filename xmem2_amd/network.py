@@ -60,6 +60,13 @@ class XMem:
         self.share_x = os.environ.get('XMEM_SHARE_X', '1') != '0'     # several objects: convolve the shared f16 half of the fusers once
         self.prefuse_x = os.environ.get('XMEM_PREFUSE_X', '1') != '0'  # prefetched frames: the decoder fuser's f16 half in the batched key pass
         self._side = None
+        # GroupResBlocks with a downsample branch (fuser block1, up_16_8.out_conv): conv1 and the downsample convolution read the same
+        # tensor and are independent - inside a captured stage the downsample CAN run on a forked stream beside conv1 (same kernels,
+        # bit-identical results, tests/test_gpu_network.py).  Measured on MI355X (round 5, profiles/r05_branch_overlap_ab.txt): it LOSES -
+        # B32 614 -> 561 frames/s, C3 283 -> 276, C4 209 -> 199: with the key pass and the early readout on their own streams the chip
+        # has no idle share for a fourth queue, and the fork / join edges serialise the captured graph.  Off (XMEM_BRANCH_OVERLAP=1 enables).
+        self.branch_overlap = os.environ.get('XMEM_BRANCH_OVERLAP', '0') != '0'
+        self._branch = None
         # scratch of the side-stream key-encoder stages is scoped to this instance and released with it
         self._scope = ops.new_scope()
         weakref.finalize(self, ops.release_scope, self._scope)
@@ -276,11 +283,15 @@ class XMem:
             # warm-up: sizes every workspace before the capture.  Inputs the stage updates in place (`mutates`: the hidden
             # state) are cloned for it, otherwise warm-up + first replay would advance the state twice.
             with ops.precision(prec):
-                fn(*[(t.clone() if (i in mutates and t is not None) else t) for i, t in enumerate(static_in)])
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    static_out = fn(*static_in)
+                self._in_stage = True            # warm-up and capture take the same (forked) launch sequence: same workspaces
+                try:
+                    fn(*[(t.clone() if (i in mutates and t is not None) else t) for i, t in enumerate(static_in)])
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        static_out = fn(*static_in)
+                finally:
+                    self._in_stage = False
             st = (graph, static_in, static_out)
             while len(self._stages) >= self.max_stages:
                 self._evict_lru()
@@ -357,9 +368,33 @@ class XMem:
     def _group_res(self, g, p, out=None, out_ld=None):
         """GroupResBlock, model/group_modules.py:44-52: conv2(relu(conv1(relu(g)))) + (downsample(g) | g)."""
         W = self._w
+        if (p + '.downsample') in W and self._fork_ok():
+            res = self._forked(lambda: ops.conv2d(g, W[p + '.downsample']))
+            o = ops.conv2d(g, W[p + '.conv1'], relu_in=True, relu_out=True)
+            self._join()
+            return ops.conv2d(o, W[p + '.conv2'], res=res, out=out, out_ld=out_ld)
         o = ops.conv2d(g, W[p + '.conv1'], relu_in=True, relu_out=True)
         res = ops.conv2d(g, W[p + '.downsample']) if (p + '.downsample') in W else g
         return ops.conv2d(o, W[p + '.conv2'], res=res, out=out, out_ld=out_ld)
+
+    # ---- forked branch inside a stage ------------------------------------------------------------
+    def _fork_ok(self):
+        """Fork only where the launches end up in a HIP graph (a stage being warmed up or captured): eager launches would pay two
+        cross-stream waits per block for nothing."""
+        return self.branch_overlap and self.use_graphs and not ops.eager_only() and getattr(self, '_in_stage', False)
+
+    def _forked(self, fn):
+        """Run fn() on the branch stream (own scratch scope: the convolution workspaces are per stream), forked from the current one."""
+        main = torch.cuda.current_stream()
+        if self._branch is None:
+            self._branch = torch.cuda.Stream(device=self.device)
+        self._branch.wait_stream(main)
+        with torch.cuda.stream(self._branch), ops.ws_scope(getattr(ops._tls, 'suffix', '') + f'@branch#{self._scope}#'):
+            out = fn()
+        return out
+
+    def _join(self):
+        torch.cuda.current_stream().wait_stream(self._branch)
 
     def _shares_x(self, p, n_obj):
         """True when `_fusion(cat, p, x)` convolves the shared x half once (several objects, split weights uploaded)."""
@@ -378,9 +413,14 @@ class XMem:
             ld, cg = cat.shape[3], cat.shape[3] - xd
             # pre = (conv1@x(relu(x)), downsample@x(x)) already made in the batched key pass (prefetched frames)
             sx = pre[0] if pre is not None else ops.conv2d(x, W[b1 + '.conv1@x'], relu_in=True)
-            o = ops.conv2d(gpart, W[b1 + '.conv1@g'], relu_in=True, relu_out=True, res=sx, res_broadcast=True, in_ld=ld, cin=cg)
             dx = pre[1] if pre is not None else ops.conv2d(x, W[b1 + '.downsample@x'])
-            res = ops.conv2d(gpart, W[b1 + '.downsample@g'], res=dx, res_broadcast=True, in_ld=ld, cin=cg)
+            if self._fork_ok():
+                res = self._forked(lambda: ops.conv2d(gpart, W[b1 + '.downsample@g'], res=dx, res_broadcast=True, in_ld=ld, cin=cg))
+                o = ops.conv2d(gpart, W[b1 + '.conv1@g'], relu_in=True, relu_out=True, res=sx, res_broadcast=True, in_ld=ld, cin=cg)
+                self._join()
+            else:
+                o = ops.conv2d(gpart, W[b1 + '.conv1@g'], relu_in=True, relu_out=True, res=sx, res_broadcast=True, in_ld=ld, cin=cg)
+                res = ops.conv2d(gpart, W[b1 + '.downsample@g'], res=dx, res_broadcast=True, in_ld=ld, cin=cg)
             g = ops.conv2d(o, W[b1 + '.conv2'], res=res)
         else:
             g = self._group_res(cat, b1)
