@@ -19,6 +19,11 @@ environment spawns the N ranks itself (xmem2_amd.launch.spawn_ranks) and refuses
 ONE JSON line.  Kernel-level numbers come from (i) HIP events on the launch stream around the eager memory-readout calls
 inside a second, instrumented pass of the timed schedule and (ii) a rocprofv3 --kernel-trace of this same command run as
 a child process and cut to the timed region with marker kernels (N=1, rank 0).
+
+Frame pipeline of `value` (all of it optional for a caller, none of it changes a result): the key encoder of the coming frames in
+batches of --key-batch on a side stream (`prefetch_keys`), the memory readout of the next prefetched frame on a third stream under
+the current frame's decoder (early readout, XMEM_EARLY_READOUT=0 turns it off), the decoder + mask output on the main stream.
+`value_no_prefetch` is the same workload through `step()` alone - the reference's call sequence.
 """
 import argparse
 import csv
@@ -819,6 +824,7 @@ def main():
             'config': {'workload': wl['desc'] + '; step()+argmax+uint8 mask to host per frame, conditioned synthetic weights',
                        'workload_key': args.workload, 'replica_streams': world, 'top_k': TOPK,
                        'frame_pipelining': (not args.no_prefetch), 'key_batch': (args.key_batch if not args.no_prefetch else 0),
+                       'early_readout': bool(getattr(res['core'], 'early_readout', False)) and not args.no_prefetch,
                        'parallelism': f'{world} independent streams, no collectives',
                        'control_plane': backend or 'none'},
             'per_rank_fps': per_rank,
