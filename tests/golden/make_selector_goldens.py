@@ -120,6 +120,37 @@ def main():
         out.update({f'{name}/keys': keys.numpy(), f'{name}/shr': shr.numpy(), f'{name}/sel': sel.numpy(),
                     f'{name}/masks': torch.stack(masks).numpy(), f'{name}/chosen': np.array(list(want), dtype=np.int64),
                     f'{name}/oracle_scores': trace, f'{name}/kwargs': np.array(repr(kw))})
+    # extract_keys (frame_selection_utils.py:11-44): the reference function over a three-frame "dataloader" with the IMPORTED reference
+    # network behind a processor that exposes encode_frame_key exactly as inference_core.py:53-61 does (InferenceCore.__init__ itself
+    # touches cuda:0 at :26, SURVEY 8c work-around 1)
+    from inference.frame_selection.frame_selection_utils import extract_keys as ref_extract
+    from inference.inference_core import InferenceCore as RefInferenceCore
+    from model.network import XMem as RefXMem
+    from xmem2_amd.synth import synthetic_frames, synthetic_state_dict
+    sd = synthetic_state_dict(0)
+    cfg = dict(mem_every=10, deep_update_every=-1, enable_long_term=True, enable_long_term_count_usage=True, hidden_dim=64, key_dim=64,
+               value_dim=512, top_k=30, max_mid_term_frames=10, min_mid_term_frames=5, num_prototypes=128, max_long_term_elements=10000,
+               model=None)
+    net = RefXMem(cfg, None, pretrained_key_encoder=False, pretrained_value_encoder=False).eval()
+    net.load_state_dict(sd)
+
+    class Core(RefInferenceCore):
+        def __init__(self, network, config):                      # inference_core.py:13-23 without the cuda:0 warm-up
+            self.config = config; self.network = network
+            self.mem_every = config['mem_every']; self.deep_update_every = config['deep_update_every']
+            self.enable_long_term = config['enable_long_term']; self.deep_update_sync = (self.deep_update_every < 0)
+            self.clear_memory(); self.all_labels = None
+
+    frames = synthetic_frames(3, 96, 128, seed=21)
+    loader = [types.SimpleNamespace(rgb=torch.from_numpy(f)) for f in frames]
+    for flatten in (True, False):
+        fk, fs, fe, dev, n, key_sum = ref_extract(loader, Core(net, cfg), flatten=flatten)
+        assert n == 3 and str(dev) == 'cpu'
+        tag = 'extract_flat' if flatten else 'extract_grid'
+        out.update({f'{tag}/keys': torch.stack(fk).numpy(), f'{tag}/shr': torch.stack(fs).numpy(), f'{tag}/sel': torch.stack(fe).numpy(),
+                    f'{tag}/key_sum': key_sum.numpy()})
+        print(f'extract_keys(flatten={flatten}): reference returned {n} frames, key {tuple(fk[0].shape)}, key_sum dtype {key_sum.dtype}')
+    out['extract/frames'] = frames
     out['names'] = np.array([s[0] for s in scenarios()])
     out['meta'] = np.array('choices recorded from the imported reference function (inference/frame_selection/frame_selection.py:99-244) behind '
                            'arithmetic-free import placeholders, masks at key resolution; torch ' + torch.__version__ + ', 1 thread')

@@ -182,3 +182,24 @@ def test_selector_hip_reproduces_the_reference_recorded_choices():
             assert list(got) == chosen, f'{name}: {got} vs the reference\'s {chosen}'
             n_decisive += 1
     assert n_decisive >= 4
+
+
+def test_extract_keys_matches_the_reference_recorded_outputs(hip_net):
+    """tests/golden/selector.npz `extract_*`: outputs of the IMPORTED reference `extract_keys` (frame_selection_utils.py:11-44) over a
+    three-frame loader with the imported reference network on the CPU.  The product's `extract_keys` over the HIP key encoder must
+    return the same structure (per-frame CPU tensors 1 x C x HW | 1 x C x h x w, frame count, fp64 key sum) and the same values to
+    fp32 round-off."""
+    from conftest import base_config, load_golden
+    from xmem2_amd import InferenceCore
+    from xmem2_amd.frame_selection import extract_keys
+    g = load_golden('selector')
+    frames = [torch.from_numpy(f) for f in g['extract/frames']]
+    core = InferenceCore(hip_net, config=base_config())
+    for flatten, tag in ((True, 'extract_flat'), (False, 'extract_grid')):
+        fk, fs, fe, device, n, key_sum = extract_keys(frames, core, flatten=flatten)
+        assert n == len(frames) == g[f'{tag}/keys'].shape[0] and key_sum.dtype == torch.float64
+        for got, name in ((fk, 'keys'), (fs, 'shr'), (fe, 'sel')):
+            want = g[f'{tag}/{name}']
+            assert not got[0].is_cuda and tuple(torch.stack(got).shape) == want.shape, (name, torch.stack(got).shape, want.shape)
+            np.testing.assert_allclose(torch.stack(got).numpy(), want, rtol=2e-3, atol=2e-4 * float(np.abs(want).max()), err_msg=f'{tag}/{name}')
+        np.testing.assert_allclose(key_sum.cpu().numpy(), g[f'{tag}/key_sum'], rtol=2e-3, atol=2e-4 * float(np.abs(g[f'{tag}/key_sum']).max()))
