@@ -281,7 +281,8 @@ def run_gpu(args, device, rank, world):
     # ---- instrumented pass (rank 0): the SAME schedule again (graphs, two streams, batched hints) with HIP events on
     # the launch stream around the memory-readout calls, which are eager launches between the captured stages
     taps, inst_frames, inst_elapsed = {}, 0, None
-    if rank == 0 and not args.traced_child and not args.scale_only:
+    skip_extra = bool(os.environ.get('XMEM_BENCH_SKIP_PASSES'))            # debugging aid: none of the instrumented passes
+    if rank == 0 and not args.traced_child and not args.scale_only and not skip_extra:
         inst_frames = min(args.steps, 100)
         ops.EVENT_TAP = []
         torch.cuda.synchronize(device)
@@ -301,7 +302,7 @@ def run_gpu(args, device, rank, world):
     # of the readout (list lengths, query tiles that needed the second pass): a few more frames of the same schedule, with a
     # device sync per frame (not part of any reported rate)
     filt, cand = None, None
-    if rank == 0 and not args.traced_child and not args.scale_only:
+    if rank == 0 and not args.traced_child and not args.scale_only and not skip_extra:
         import ctypes as C
         from xmem2_amd._lib import load
         lib = load()
@@ -347,7 +348,7 @@ def run_gpu(args, device, rank, world):
     # eagerly with ops.RECORD on (every conv2d call notes its shape, plan, algorithmic FLOPs and the MFMA FLOPs that plan issues:
     # direct form padded to its tile, F(2x2) 16 / F(4x4) 36 position GEMMs); not part of any reported rate
     conv_survey = None
-    if rank == 0 and not args.traced_child and not args.scale_only:
+    if rank == 0 and not args.traced_child and not args.scale_only and not skip_extra:
         start = ((args.warmup + args.steps + inst_frames + 400) // KB + 1) * KB
         hint(start)                                                  # consumed by the recorded frames; ITS convolutions are not recorded
         ops.RECORD = []
@@ -528,7 +529,12 @@ def run_cpu_baseline(res, args, device):
     labels = list(range(1, wl['K'] + 1))
     ref.set_all_labels(labels)
     fr, mk, base = res['frames'], res['masks_in'], res['base']
-    gpu = InferenceCore(res['core'].network, cfg)
+    pnet = res['core'].network
+    if os.environ.get('XMEM_BENCH_PARITY_FRESH_NET'):                      # debugging aid
+        from xmem2_amd import XMem
+        pnet = XMem(dict(cfg, precision=args.precision), None).to(device).eval()
+        pnet.load_weights(res['sd'])
+    gpu = InferenceCore(pnet, cfg)
     gpu.set_all_labels(labels)
     all_threads = torch.get_num_threads()
     torch.set_num_threads(min(all_threads, 32))
@@ -552,6 +558,40 @@ def run_cpu_baseline(res, args, device):
             hint(i + KB)
         gpu_out.append((ops.argmax_u8(pg).cpu().numpy(), pg[:, 4::8, 4::8].cpu()))
     gpu.cancel_prefetch()
+    if os.environ.get('XMEM_BENCH_PARITY_TRACE'):
+        # debugging aid: the same GPU stream again (fresh cores on the same network, preload without CPU work in between) with the early
+        # readout on and off, each compared with the stream above
+        def again(early):
+            g2 = InferenceCore(pnet, cfg); g2.early_readout = early
+            g2.set_all_labels(labels)
+            for j in range(wl['perm']):
+                g2.put_to_permanent_memory(torch.from_numpy(fr[j]).to(device), torch.from_numpy(mk[j]).to(device))
+            g2.prefetch_keys(dev[0:KB]) if not args.no_prefetch else None
+            o = []
+            for i in range(n_total):
+                q = g2.step(dev[i], None, None)
+                if i % KB == 0 and not args.no_prefetch:
+                    g2.prefetch_keys(dev[i + KB:i + 2 * KB])
+                o.append(ops.argmax_u8(q).cpu().numpy())
+            g2.cancel_prefetch()
+            return o
+        for early in (True, False):
+            o = again(early)
+            print(f'[parity] GPU stream again, early_readout={early}: pixels that differ from the first GPU stream per frame: '
+                  + ' '.join(str(int((a != b[0]).sum())) for a, b in zip(o, gpu_out)), file=sys.stderr)
+    if os.environ.get('XMEM_BENCH_PARITY_TRACE'):                         # debugging aid: were the device-resident inputs touched?
+        torch.cuda.synchronize(device)
+        host = torch.from_numpy(fr)
+        bad = []
+        for i in range(min(32, n_total)):
+            d = frame_fn(i).cpu()
+            h = host[base + (i % res['n_query'])]
+            if not torch.equal(d, h):
+                bad.append((i, int((d != h).sum())))
+        print(f'[parity] device input frames that differ from their host originals after the GPU stream: {bad[:12]}', file=sys.stderr)
+        bad = [(i, int((dev[i].cpu() != host[base + (i % res["n_query"])]).sum())) for i in range(len(dev))
+               if not torch.equal(dev[i].cpu(), host[base + (i % res['n_query'])])]
+        print(f'[parity] cloned input frames that differ: {bad[:12]}', file=sys.stderr)
     del dev
     ious, mism, perr, clear_mism, near_tie, tight_mism = [], 0, 0.0, 0, 0, 0
     cpu_masks, cpu_probs, cpu_margins = [], [], []
@@ -637,6 +677,8 @@ def run_cpu_baseline(res, args, device):
                      note='clip-level IoU per object and argmax mismatch over the same frames; the reference path at two thread counts '
                           'differs from itself by the first entry (tests/test_gpu_e2e.py gates the GPU path against 1.5x that floor)')
     torch.set_num_threads(all_threads)
+    if os.environ.get('XMEM_BENCH_PARITY_TRACE'):
+        print('[parity] per-frame IoU vs the CPU path: ' + ' '.join(f'{v:.4f}' for v in ious), file=sys.stderr)
     fps = 1.0 / float(np.median(ts))
     return dict(value=fps, unit='frames/s', cores=best_t, kind='port',
                 one_thread_fps=sweep_fps.get(1), thread_sweep_fps={str(k): v for k, v in sweep_fps.items()},
