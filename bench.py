@@ -20,9 +20,10 @@ ONE JSON line.  Kernel-level numbers come from (i) HIP events on the launch stre
 inside a second, instrumented pass of the timed schedule and (ii) a rocprofv3 --kernel-trace of this same command run as
 a child process and cut to the timed region with marker kernels (N=1, rank 0).
 
-Frame pipeline of `value` (all of it optional for a caller, none of it changes a result): the key encoder of the coming frames in
-batches of --key-batch on a side stream (`prefetch_keys`), the memory readout of the next prefetched frame on a third stream under
-the current frame's decoder (early readout, XMEM_EARLY_READOUT=0 turns it off), the decoder + mask output on the main stream.
+Frame pipeline of `value` (optional for a caller, changes no result): the key encoder of the coming frames in batches of --key-batch on
+a side stream (`prefetch_keys`), readout + decoder + mask output on the main stream.  XMEM_EARLY_READOUT=1 additionally runs the memory
+readout of the next prefetched frame on a third stream under the current frame's decoder (opt-in: DESIGN.md 4.7; `config.early_readout`
+says whether a line used it).
 `value_no_prefetch` is the same workload through `step()` alone - the reference's call sequence.
 """
 import argparse
