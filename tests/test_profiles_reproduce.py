@@ -1,5 +1,5 @@
 """The trace-derived figures of the committed B32 bench line must follow from the committed trace (VERDICT round 3, item 2:
-`roofline.frac` reproducible from `profiles/`): `profiles/r04_bench_b32_timed_region_kernel_trace.csv` is the rocprofv3 kernel trace
+`roofline.frac` reproducible from `profiles/`): `profiles/r0N_bench_b32_timed_region_kernel_trace.csv` (round 4 and round 5) is the rocprofv3 kernel trace
 of the line's traced child cut to its timed region; this test re-derives `roofline.achieved / frac` (mean and median), the
 conv-family time of `conv_roofline` and the family table from it with bench.py's own parser.  No GPU, no reference."""
 import json
@@ -11,12 +11,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PROF = os.path.join(ROOT, 'profiles')
-LINE, TRACE = os.path.join(PROF, 'r04_bench_b32.json'), os.path.join(PROF, 'r04_bench_b32_timed_region_kernel_trace.csv')
 
 
-@pytest.mark.skipif(not (os.path.exists(LINE) and os.path.exists(TRACE)), reason='round-4 profiles not present')
-def test_b32_roofline_follows_from_the_committed_trace():
+@pytest.mark.parametrize('rnd', ['r04', 'r05'])
+def test_b32_roofline_follows_from_the_committed_trace(rnd):
     import bench
+    LINE, TRACE = os.path.join(PROF, f'{rnd}_bench_b32.json'), os.path.join(PROF, f'{rnd}_bench_b32_timed_region_kernel_trace.csv')
+    if not (os.path.exists(LINE) and os.path.exists(TRACE)):
+        pytest.skip(f'{rnd} profiles not present')
     line = json.loads(open(LINE).read().strip().splitlines()[-1])
     tr = bench.parse_kernel_trace(TRACE)
     r, c = line['roofline'], line['conv_roofline']
@@ -40,20 +42,25 @@ def test_b32_roofline_follows_from_the_committed_trace():
     assert c['achieved'] == pytest.approx(c['executed_mfma_gflop_per_frame'] / (conv_us * 1e-3), rel=1e-6)
     assert c['frac'] == pytest.approx(c['achieved'] / bench.PEAK_FP32_MFMA_TFLOPS, rel=1e-6)
     assert sum(v['executed_mfma_gflop'] for v in c['executed_by_form'].values()) == pytest.approx(c['executed_mfma_gflop_per_frame'], rel=1e-6)
+    if rnd >= 'r05':                                            # schema 5: the select as a whole against the pipe its contraction runs on
+        aff_us = tr['families']['affinity'][1] / frames / 1e3
+        assert r['call_frac'] == pytest.approx(r['algorithmic_gflop_per_frame'] / (aff_us * 1e-3) / bench.PEAK_F16_MFMA_TFLOPS, rel=1e-6)
+        assert line['schema'] == bench.SCHEMA and line['parity']['clear_margin'] == bench.CLEAR_MARGIN
+        assert line['config']['early_readout'] is False      # the headline does not use the opt-in schedule
     # the per-frame table committed beside the trace is the same parse
-    table = open(os.path.join(PROF, 'r04_bench_b32_timed_region_per_frame.csv')).read()
+    table = open(os.path.join(PROF, f'{rnd}_bench_b32_timed_region_per_frame.csv')).read()
     assert f'conv,{tr["families"]["conv"][0] / frames:.2f},{conv_us:.1f}' in table
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(PROF, 'r04_bench_b32_pmc_per_frame.json')), reason='round-4 profiles not present')
+@pytest.mark.skipif(not os.path.exists(os.path.join(PROF, 'r05_bench_b32_pmc_per_frame.json')), reason='round-5 profiles not present')
 def test_pmc_figures_are_quoted_only_at_the_digest_they_were_measured_at():
     """bench.py quotes `traffic` only while the PMC file's digest matches the kernel sources + compiler flags of the tree; after a
     kernel edit it reports null until the passes are repeated (tools/pmc_bench.py)."""
     import bench
     from xmem2_amd import build
-    pmc = json.load(open(os.path.join(PROF, 'r04_bench_b32_pmc_per_frame.json')))
+    pmc = json.load(open(os.path.join(PROF, 'r05_bench_b32_pmc_per_frame.json')))
     quoted = bench.committed_pmc('b32', 'fp32')
     if pmc['source_digest'] == build.source_digest():
         assert quoted is not None and quoted['families']['conv'] > 3e9 and quoted['families']['affinity'] > 5e7
     else:
-        assert quoted is None or quoted['file'] != 'profiles/r04_bench_b32_pmc_per_frame.json'
+        assert quoted is None or quoted['file'] != 'profiles/r05_bench_b32_pmc_per_frame.json'
