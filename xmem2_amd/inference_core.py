@@ -319,17 +319,21 @@ class InferenceCore:
             after = torch.cuda.Event()
             after.record(main)
         R = self._ro_stream
-        R.wait_event(nxt['event'])                    # the side stream finished that frame's key encoder
-        R.wait_event(after)
         # the decoder variant the next step() will most likely run (no mask, not the last frame): its static input buffer
         nxt_mem = (self.curr_ti + 1 - self.last_mem_ti >= self.mem_every)
         nxt_deep = (self.deep_update_sync and nxt_mem) or \
                    (not self.deep_update_sync and self.curr_ti + 1 - self.last_deep_update_ti >= self.deep_update_every)
         h_out = (not self.deep_update_sync) or (not nxt_deep)
         pending = []
+        # only into the STATIC input buffer of a decoder stage that is already captured for that slot: while an owner's stages are
+        # still being captured (its first frames) the readout stays in its step - no scratch copies of the decoder input on this stream
+        cat16 = net.new_decoder_input(K, h, w, f16.device, slot=nxt['slot'], owner=self._uid, h_out=h_out,
+                                      has_skips=len(nxt['outs']) > 6 and nxt['outs'][6] is not None, static_only=True)
+        if cat16 is None:
+            return
+        R.wait_event(nxt['event'])                    # the side stream finished that frame's key encoder
+        R.wait_event(after)
         with torch.cuda.stream(R), ops.ws_scope(f'@early#{self._uid}#'):
-            cat16 = net.new_decoder_input(K, h, w, f16.device, slot=nxt['slot'], owner=self._uid, h_out=h_out,
-                                          has_skips=len(nxt['outs']) > 6 and nxt['outs'][6] is not None)
             ld = cat16.shape[3]
             mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024, defer_usage=pending)
             done = torch.cuda.Event()
@@ -346,9 +350,8 @@ class InferenceCore:
         main.wait_event(e['done'])
         ok = pf is not None and e['pf'] is pf and e['mem'] is mem and e['version'] == mem.version and e['K'] == K \
             and tuple(e['cat16'].shape) == tuple(cat16.shape) and e['cat16'].dtype == cat16.dtype
-        for _, w_, idx_, _ in e['pending']:
+        for _, w_, idx_, _ in e['pending']:           # allocated on the readout stream, consumed (usage update) on this one
             w_.record_stream(main); idx_.record_stream(main)
-        e['cat16'].record_stream(main)
         return e if ok else None
 
     def _retire_early(self):

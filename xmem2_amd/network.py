@@ -553,9 +553,10 @@ class XMem:
             ops.copy_channels(g, cat, f16.shape[3])
             return self._fusion(cat, 'value_encoder.fuser', x=None)
 
-    def new_decoder_input(self, K, h, w, device, slot=0, owner=0, h_out=None, has_skips=None):
+    def new_decoder_input(self, K, h, w, device, slot=0, owner=0, h_out=None, has_skips=None, static_only=False):
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
-        Once the matching decoder stage is captured this is its static input buffer (no copy before the replay)."""
+        Once the matching decoder stage is captured this is its static input buffer (no copy before the replay).
+        static_only: None instead of a fresh buffer when no captured stage matches."""
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
         prec = self._call_precision or self.precision
         if self.use_graphs and not ops.eager_only():
@@ -566,6 +567,8 @@ class XMem:
                 if (h_out is not None and k[1][2] != bool(h_out)) or (has_skips is not None and k[1][3] != bool(has_skips)):
                     continue
                 return st[1][3]
+        if static_only:
+            return None
         return torch.empty(shape, dtype=torch.float16 if prec == 'fp16' else torch.float32, device=device)
 
     def _zero_scratch(self, shape, device, dtype=torch.float32):
