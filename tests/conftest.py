@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 torch.set_grad_enabled(False)
+if os.environ.get('XMEM_POISON_EMPTY'):
+    # debugging aid: every torch.empty (activations, arenas, scratch) comes back filled with NaN / 0xFF instead of whatever the allocator
+    # held - a read of memory nobody wrote shows up as NaN in the outputs instead of depending on the allocation history
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
 
 
 def pytest_configure(config):

