@@ -766,6 +766,11 @@ def parse_args(argv=None):
 
 def main():
     args = parse_args()
+    if os.environ.get('XMEM_POISON_EMPTY'):
+        # debugging aid: torch.empty returns NaN / 0xFF-filled memory instead of whatever the allocator held (activations, arenas, scratch):
+        # a read of memory nobody wrote shows up as NaN instead of depending on the allocation history.  Slower; never for a reported rate.
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 or args.gpus > 1:
         args.scale_only = True                     # a scaling run measures the timed region only, on every rank alike
     if args.scale_only:
