@@ -187,7 +187,7 @@ def test_early_readout_is_only_a_schedule(hip_net, n_obj):
 
     p0, s0, n0 = run(False)
     p1, s1, n1 = run(True)
-    assert n0 == 0 and n1 >= 4, (n0, n1)                       # the early path really ran
+    assert n0 == 0 and n1 >= 3, (n0, n1)                       # the early path really ran
     assert s0[2] > 0, 'the clip must contain a consolidation'
     for i, (a, b) in enumerate(zip(p0, p1)):
         assert torch.equal(a, b), f'frame {i + 1}: probabilities differ (max {float((a - b).abs().max()):.2e})'
