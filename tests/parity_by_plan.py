@@ -25,7 +25,7 @@ from xmem2_amd.synth import synthetic_state_dict  # noqa: E402
 
 def main():
     sds = {None: synthetic_state_dict(0), 'multi_object': synthetic_state_dict(0, conditioning='multi_object')}
-    clips = [U.c3_clip(), U.golden_clip('240p_2obj', (240, 427), 2)]
+    clips = [U.c3_clip(), U.golden_clip('240p_2obj', (240, 427), 2), U.c3_bench_clip()]
     if len(sys.argv) > 1:                                        # e.g. `parity_by_plan.py 240p_2obj`: only the named clips
         clips = [c for c in clips if c.name in sys.argv[1:]]
     print(f'device {torch.cuda.get_device_name(0)}; oracle threads: 1 (the goldens\' count) and 8; host cores {os.cpu_count()}')

@@ -378,6 +378,33 @@ def test_e2e_480p_three_objects_consolidation_vs_oracle(hip_net_mo, ref_net_mo):
         _noise_floor_gate(tag, g, phases[ph], frac_cap=max(1e-4, 1.5 * floor['mismatch'] / floor['pixels']), floor_deficit=worst)
 
 
+def test_e2e_480p_three_objects_bench_c3_stream_vs_oracle(hip_net_mo, ref_net_mo):
+    """The stream `bench.py --workload c3` itself (25 frames, one permanent frame, mem_every=5: five memory frames carry PREDICTED
+    masks back into the memory) under the noise-floor gate.  Round 5's bench print on this clip was 119 px / IoU 0.99848 against the
+    oracle's own 32 px / 0.99939 - outside the gate this test applies; it was only a bench print then."""
+    import clip_util as U
+    clip = U.c3_bench_clip()
+    o1, p1, s1 = U.run_oracle(ref_net_mo, clip, 1)
+    o8, _, _ = U.run_oracle(ref_net_mo, clip, 8)
+    a, p, s = U.run_gpu(hip_net_mo, clip)
+    assert s == s1, 'memory sizes differ from the oracle'
+    gpu, floor = U.compare(a, o1, clip.labels), U.compare(o8, o1, clip.labels)
+    print(f'bench c3 stream ({len(a)} frames):\n   HIP    vs oracle(1 thr): {U.fmt(gpu)}\n   oracle(8 thr) vs (1 thr): {U.fmt(floor)}')
+    # at SURVEY 8(c)'s margin: where the oracle's own top-2 margin exceeds 2e-3 the GPU path may differ on no more pixels than 1.5x the oracle
+    # differs from itself there (+ a handful)
+    def at_margin(x):
+        n = 0
+        for i in range(len(x)):
+            t2 = torch.topk(p1[i], 2, dim=0).values
+            n += int(((x[i] != o1[i]) & ((t2[0] - t2[1]).numpy() > 2e-3)).sum())
+        return n
+    g_m, f_m = at_margin(a), at_margin(o8)
+    print(f'   at a top-2 margin > 2e-3 of oracle(1 thr): HIP {g_m} px, oracle(8 thr) {f_m} px')
+    _noise_floor_gate('bench c3 stream', gpu, floor, frac_cap=0.0)
+    assert min(gpu['iou']) >= 0.999, f"north_star: IoU >= 0.999 per object, got {gpu['iou']}"
+    assert g_m <= 1.5 * f_m + 8, f'argmax mismatch at the 2e-3 margin: HIP {g_m} px vs the oracle\'s own {f_m}'
+
+
 def test_e2e_240p_two_objects_noise_floor(hip_net, ref_net):
     """The 240p two-object golden clip (object 1 is ~1800 px) with the reference's own noise floor next to it: oracle at 8
     threads vs the 1-thread goldens on the same frames, then the HIP path under the same gate as config 3."""

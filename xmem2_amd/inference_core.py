@@ -29,6 +29,27 @@ def _on_network_device(fn):
     return wrapper
 
 
+def _release_core(network, uid, inflight):
+    """Finalizer of an InferenceCore: work it enqueued on the side / readout streams (a batched key pass into the network's shared
+    key-stage buffers, a readout into a decoder stage's static input) must be over before its owner token is recycled."""
+    for ev in inflight.values():
+        if ev is not None:
+            try:
+                ev.synchronize()
+            except Exception:
+                pass
+    network.release_owner(uid)
+
+
+def _net_stream(net, name, make):
+    """Side streams live on the NETWORK, not on the core: the key-stage buffers of a slot and the decoder stages' static inputs belong
+    to the network, so successive (or concurrent) cores on one network are stream-ordered against each other on them."""
+    d = net.__dict__.setdefault('_core_streams', {})
+    if name not in d:
+        d[name] = make()
+    return d[name]
+
+
 class InferenceCore:
     def __init__(self, network, config):
         self.config = config
@@ -52,11 +73,14 @@ class InferenceCore:
         # with and without early readout - was right (profiles/r05_early_readout_ab.txt).  Not understood, so not the default.
         self._ro_stream = None
         self._early = None
-        self.early_readout = os.environ.get('XMEM_EARLY_READOUT', '0') != '0'
+        self.early_readout = os.environ.get('XMEM_EARLY_READOUT', '1') != '0'
+        # latest events of this core's work on the side / readout streams: the finalizer waits for them before the owner token (and with
+        # it the captured decoder stages and their static buffers) goes to the next core
+        self._inflight = {'side': None, 'early': None}
         # owner token of this core's captured decoder stages (they update ITS hidden state in place); recycled when the core dies
         if hasattr(network, 'acquire_owner'):
             self._uid = network.acquire_owner()
-            weakref.finalize(self, network.release_owner, self._uid)
+            weakref.finalize(self, _release_core, network, self._uid, self._inflight)
         else:
             self._uid = id(self)
         # warm-up on the network's own device (the reference hard-codes cuda:0, inference_core.py:26)
@@ -82,10 +106,12 @@ class InferenceCore:
 
     def update_config(self, config):
         """inference_core.py:40-47."""
+        self._retire_early()
         self._read_config(config)
         self.memory.update_config(config)
 
     def set_all_labels(self, all_labels):
+        self._retire_early()
         self.all_labels = all_labels
 
     # ---- helpers ---------------------------------------------------------------------------------
@@ -127,22 +153,28 @@ class InferenceCore:
         key, shr, sel, f16, _, _ = self.network.encode_key_nhwc(image4, need_sk=True, need_ek=True)
         return tuple(v.clone() for v in self._key_views(key, shr, sel, f16.shape[1], f16.shape[2]))
 
-    def prefetch_key(self, image):
+    def prefetch_key(self, image, inputs_complete=False):
         """Enqueue the key encoder for the NEXT frame (see `prefetch_keys`); returns the device tensor to hand to
         the next `step()`."""
-        return self.prefetch_keys([image])[0]
+        return self.prefetch_keys([image], inputs_complete=inputs_complete)[0]
 
     @_on_network_device
-    def prefetch_keys(self, images):
+    def prefetch_keys(self, images, inputs_complete=False):
         """Enqueue ONE batched key-encoder pass for the next `len(images)` frames on a side stream.
 
         The key encoder depends on nothing but the image, so a streaming caller that already holds the coming frames
         (the reference's DataLoader does, inference/run_on_video.py:80-92) can hint them: the pass runs in its own HIP
         graph and scratch while the current frames are still being read out / decoded on the main stream, and a batch
         of frames amortises the launch-bound 1/16-resolution layers (1.16 -> 0.82 ms per frame at batch 4).  `images`:
-        3 x H x W float32 (or decoded H x W x 3 uint8) tensors of one shape, pinned-CPU or device tensors that are complete.  Returns the
+        3 x H x W float32 (or decoded H x W x 3 uint8) tensors of one shape, pinned-CPU or device tensors.  Returns the
         device tensors to pass to the following `step()` calls IN ORDER; a `step()` on any other tensor simply drops
-        the pending hints.  Not part of the reference surface: `step()` computes the same function without it."""
+        the pending hints.  Not part of the reference surface: `step()` computes the same function without it.
+
+        DEVICE inputs are read on the side stream.  By default the side stream first waits for everything enqueued so far on the
+        CALLER's current stream, so a tensor the caller has just produced there (a `.clone()`, a resize, an H2D copy) is complete when
+        the pass reads it.  `inputs_complete=True` skips that wait for callers whose inputs were finished long ago (resident clips):
+        the pass may then start under the frame that is still being decoded.  (Round 6: bench.py's parity leg handed over clones that
+        were still being written on the main stream - the 'unexplained wrong stream' of round 5)"""
         net = self.network
         images = list(images)
         if not images:
@@ -153,7 +185,9 @@ class InferenceCore:
             raise ValueError('prefetch_keys: all frames of a batch must have the same shape')
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = ops.side_stream(net.device)
+            self._side = _net_stream(net, 'side', lambda: ops.side_stream(net.device))
+        if not inputs_complete and any(im.is_cuda for im in images):
+            self._side.wait_stream(main)                         # producers of the inputs on the caller's stream
         B = len(images)
         par = self._group_parity.get(B, 1) ^ 1                   # two buffer groups per batch size, used alternately
         gid = ('g', B, par)
@@ -174,6 +208,7 @@ class InferenceCore:
             outs = net.encode_key_nhwc(image4, need_sk=True, need_ek=True, with_skips=True, slot=gid, inline_skips=True)
             ev = torch.cuda.Event()
             ev.record(self._side)
+        self._inflight['side'] = ev
         if saved_pad is not None:
             self.pad = saved_pad
         for t in [image4] + devs:
@@ -215,6 +250,8 @@ class InferenceCore:
             is_mem_frame = ((self.curr_ti - self.last_mem_ti >= self.mem_every) or (mask is not None)) and (not end)
         is_ignore = do_not_add_mask_to_memory
         need_segment = (valid_labels is None) or (len(self.all_labels) != len(valid_labels))
+        if self._early is not None and not (need_segment and pf is not None and self._early['pf'] is pf):
+            self._retire_early()          # not this step's to consume: wait for it before this step touches the memory / key buffers
         is_deep_update = ((self.deep_update_sync and is_mem_frame) or
                           (not self.deep_update_sync and self.curr_ti - self.last_deep_update_ti >= self.deep_update_every)
                           ) and (not end)
@@ -241,7 +278,7 @@ class InferenceCore:
             hidden = mem.get_hidden()
             K = hidden.shape[0]
             cat16 = net.new_decoder_input(K, h, w, f16.device, slot=slot, owner=self._uid, h_out=is_normal_update,
-                                          has_skips=skips is not None)
+                                          has_skips=skips is not None, out_hw=hw, pad_tl=(self.pad[2], self.pad[0]))
             ld = cat16.shape[3]
             early = self._take_early(pf, mem, K, cat16)
             if early is not None:
@@ -314,7 +351,7 @@ class InferenceCore:
         h, w, K = f16.shape[1], f16.shape[2], hidden.shape[0]
         main = torch.cuda.current_stream()
         if self._ro_stream is None:
-            self._ro_stream = torch.cuda.Stream(device=net.device)
+            self._ro_stream = _net_stream(net, 'readout', lambda: torch.cuda.Stream(device=net.device))
         if after is None:
             after = torch.cuda.Event()
             after.record(main)
@@ -328,7 +365,8 @@ class InferenceCore:
         # only into the STATIC input buffer of a decoder stage that is already captured for that slot: while an owner's stages are
         # still being captured (its first frames) the readout stays in its step - no scratch copies of the decoder input on this stream
         cat16 = net.new_decoder_input(K, h, w, f16.device, slot=nxt['slot'], owner=self._uid, h_out=h_out,
-                                      has_skips=len(nxt['outs']) > 6 and nxt['outs'][6] is not None, static_only=True)
+                                      has_skips=len(nxt['outs']) > 6 and nxt['outs'][6] is not None, static_only=True,
+                                      out_hw=nxt['hw'], pad_tl=(nxt['pad'][2], nxt['pad'][0]))
         if cat16 is None:
             return
         R.wait_event(nxt['event'])                    # the side stream finished that frame's key encoder
@@ -338,6 +376,7 @@ class InferenceCore:
             mem.match_memory_rows(key, selection, cat16, ld, h * w * ld, out_off=1024, defer_usage=pending)
             done = torch.cuda.Event()
             done.record(R)
+        self._inflight['early'] = done
         self._early = dict(pf=nxt, mem=mem, version=mem.version, K=K, cat16=cat16, pending=pending, done=done)
 
     def _take_early(self, pf, mem, K, cat16):
@@ -439,6 +478,7 @@ class InferenceCore:
         return B
 
     def remove_from_permanent_memory(self, frame_idx):
+        self._retire_early()                          # a readout enqueued ahead is reading the store that is about to shrink
         self.memory.remove_from_permanent_memory(frame_idx)
 
     @property

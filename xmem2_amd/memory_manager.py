@@ -107,6 +107,10 @@ class MemoryManager:
             hint = self._aff_hint.get(gi) if self.use_affinity_hint else None
             if hint is not None and (hint[0].shape[0] != qk.shape[0] or len(hint[1]) != len(sizes)):
                 hint = None
+            if hint is not None and hint[0].is_cuda:
+                # the previous call may have run (and allocated its outputs) on another stream - the readout stream of a core, or the
+                # main one: tell the allocator this stream reads the indices, so that their block is not handed out while it does
+                hint[0].record_stream(torch.cuda.current_stream())
             w, idx, _ = ops.affinity_topk(segs, qk, qe, self.top_k, hint=hint)
             self._aff_hint[gi] = (idx, sizes, self.W if self.W else 0)
             if gi == 0 and self.enable_long_term and not disable_usage_updates:

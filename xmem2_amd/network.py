@@ -553,10 +553,11 @@ class XMem:
             ops.copy_channels(g, cat, f16.shape[3])
             return self._fusion(cat, 'value_encoder.fuser', x=None)
 
-    def new_decoder_input(self, K, h, w, device, slot=0, owner=0, h_out=None, has_skips=None, static_only=False):
+    def new_decoder_input(self, K, h, w, device, slot=0, owner=0, h_out=None, has_skips=None, static_only=False, out_hw=None, pad_tl=None):
         """[K,h,w, 1024+Cv+Ch] buffer; the readout kernel writes channels [1024, 1024+Cv) in place.
         Once the matching decoder stage is captured this is its static input buffer (no copy before the replay).
-        static_only: None instead of a fresh buffer when no captured stage matches."""
+        static_only: None instead of a fresh buffer when no captured stage matches.  out_hw / pad_tl: the remaining components of the
+        stage key (two resolutions that pad to one h x w have stages of their own)."""
         shape = (K, h, w, 1024 + self.value_dim + self.hidden_dim)
         prec = self._call_precision or self.precision
         if self.use_graphs and not ops.eager_only():
@@ -565,6 +566,8 @@ class XMem:
                         or tuple(st[1][3].shape) != shape:
                     continue
                 if (h_out is not None and k[1][2] != bool(h_out)) or (has_skips is not None and k[1][3] != bool(has_skips)):
+                    continue
+                if (out_hw is not None and k[1][0] != tuple(out_hw)) or (pad_tl is not None and k[1][1] != tuple(pad_tl)):
                     continue
                 return st[1][3]
         if static_only:
