@@ -221,8 +221,10 @@ def run_gpu(args, device, rank, world):
 
     def hint(first):                                 # batched key encoder of frames [first, first+KB) on the side stream
         if not args.no_prefetch:
-            # resident clip: the inputs were finished long ago (motion workloads build their frames on the main stream on first use)
-            core.prefetch_keys([frame(first + j) for j in range(KB)], inputs_complete=not wl.get('motion'))
+            # the default, safe form (the side stream waits for this stream's tail before it reads device inputs): measured free,
+            # 611-612 frames/s either way (profiles/r06_early_readout_root_cause.txt); XMEM_BENCH_UNSAFE_HINTS=1 is the A/B knob
+            core.prefetch_keys([frame(first + j) for j in range(KB)],
+                               inputs_complete=bool(os.environ.get('XMEM_BENCH_UNSAFE_HINTS')) and not wl.get('motion'))
 
     host_t = {'step': 0.0, 'hint': 0.0, 'fetch': 0.0, 'n': 0} if os.environ.get('XMEM_BENCH_HOST_TIMES') else None
 
@@ -519,6 +521,24 @@ def committed_pmc(workload, precision='fp32'):
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------
+def _physical_cores():
+    """Physical cores of the host (distinct (package, core id) pairs of /proc/cpuinfo), or None."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def run_cpu_baseline(res, args, device):
     """The oracle (CPU restatement, bit-equal to the imported reference in the build container) on the same workload on
     this box's host cores.  Protocol (bounded to keep the default run within minutes): thread sweep
@@ -682,7 +702,9 @@ def run_cpu_baseline(res, args, device):
     if os.environ.get('XMEM_BENCH_PARITY_TRACE'):
         print('[parity] per-frame IoU vs the CPU path: ' + ' '.join(f'{v:.4f}' for v in ious), file=sys.stderr)
     fps = 1.0 / float(np.median(ts))
-    return dict(value=fps, unit='frames/s', cores=best_t, kind='port',
+    return dict(value=fps, unit='frames/s', cores=best_t, threads=best_t, host_physical_cores=_physical_cores(), kind='port',
+                cores_note='cores = threads = the torch thread count of the best sweep point (what the contract calls cores: the threads actually used); '
+                           'host_physical_cores / host_logical_cpus describe the box',
                 one_thread_fps=sweep_fps.get(1), thread_sweep_fps={str(k): v for k, v in sweep_fps.items()},
                 host_logical_cpus=os.cpu_count(), frames_timed=len(ts), statistic='median',
                 sample=f'{wl["desc"]}: {wl["perm"]} permanent frames preloaded (untimed); thread sweep {sweep} '

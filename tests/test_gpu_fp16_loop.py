@@ -202,7 +202,8 @@ def test_fp16_loop_end_to_end_vs_fp32_goldens(synth_sd, tag, hw, n_obj, min_iou,
     both = [float(((got == c) & (fl['argmax_net_only'] == c)).sum() / max(((got == c) | (fl['argmax_net_only'] == c)).sum(), 1)) for c in labels]
     print(f'fp16 loop, {tag}: the autocast policy restated on the CPU vs the fp32 goldens: IoU {[round(v, 5) for v in floor_iou]}, mismatch {floor_mism:.2e} '
           f'(network only, fp32 memory matmuls: {[round(v, 5) for v in net_iou]}, {net_mism:.2e}); this loop vs that network-only restatement: IoU {[round(v, 5) for v in both]}')
-    assert all(v >= f for v, f in zip(iou, floor_iou)), f'fp16 loop IoU {iou} below the autocast restatement\'s own {floor_iou}'
+    # (where the restatement's own floor is low - 0.650 on the 1 872-pixel object of the 240p clip - the mode's own gate `min_iou` is the one that binds)
+    assert all(v >= max(f, m) for v, f, m in zip(iou, floor_iou, min_iou)), f'fp16 loop IoU {iou} below max(autocast restatement {floor_iou}, own gate {min_iou})'
     assert mism <= floor_mism, f'fp16 loop mismatch {mism:.2e} above the autocast restatement\'s own {floor_mism:.2e}'
     assert perr <= float(fl['worst_mean_abs_dp_full']), (perr, float(fl['worst_mean_abs_dp_full']))
     # what the mode guarantees: probabilities within fp16 noise, hence the same argmax wherever the reference's own top-2 margin is

@@ -1178,8 +1178,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         a.limit = pl.limit; a.cap = pl.cap; a.splits = pl.splits; a.tiles_per_split = pl.tiles_per_split; a.sub_tiles = pl.sub_tiles;
         a.tile_stride = 1; a.chunk = 0;
         auto kern = affinity_kernel<64, 2>;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess)
-            return XMEM_ERR_LAUNCH;
+        if ((rc = xmem_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.lds)) != XMEM_OK) return rc;
         hipLaunchKernelGGL(kern, dim3(cdiv(HW, AFF_BQ), pl.splits), dim3(256), pl.lds, s, a);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         const size_t mlds = ((size_t)pl.splits * AFF_OUTCAP + 2) * sizeof(u64) + (size_t)2 * top_k * sizeof(float);
@@ -1261,8 +1260,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
     }
     {
         const size_t lds = ((size_t)AFW_BQ * AFF_LDB + 3 * AFW_BQ + 4) * sizeof(float) + (size_t)AFW_BQ * AFW_CAP * sizeof(u64);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(affinity_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
+        if ((rc = xmem_ensure_dynamic_lds(reinterpret_cast<const void*>(affinity_wide_kernel), lds)) != XMEM_OK) return rc;
         hipLaunchKernelGGL(affinity_wide_kernel, dim3(qt128, w.splits), dim3(512), lds, s, w);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     }

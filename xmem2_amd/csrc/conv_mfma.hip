@@ -1127,10 +1127,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, int groups = 1, bool split = fa
         kern = conv_mfma_kernel<BM, BN, TM, TN, BK, G, false, true>;
         if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true, true>;
     } else if (!G && conv_is_one(a)) kern = conv_mfma_kernel<BM, BN, TM, TN, BK, false, true, false>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
-    }
+    if (xmem_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != XMEM_OK) return XMEM_ERR_LAUNCH;
     dim3 grid(a.tiles_m * a.tiles_n, groups, a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return xmem_check_launch();
@@ -1145,7 +1142,7 @@ int launch_half_256(const ConvArgs& a, hipStream_t s, int half) {
     auto kern = conv_mfma_kernel<256, 128, 2, 2, 32, G, false, false, 2, 8>;
     if (half == 2) { if (one) kern = conv_mfma_kernel<256, 128, 2, 2, 32, false, true, false, 2, 8>; }
     else kern = one ? conv_mfma_kernel<256, 128, 2, 2, 32, false, true, false, 1, 8> : conv_mfma_kernel<256, 128, 2, 2, 32, G, false, false, 1, 8>;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XMEM_ERR_LAUNCH;
+    if (xmem_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != XMEM_OK) return XMEM_ERR_LAUNCH;
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.splitk);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
     return xmem_check_launch();

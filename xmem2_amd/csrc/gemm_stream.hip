@@ -292,10 +292,7 @@ template <int TM, int TN, int NS>
 int launch_variant(const GemmStreamArgs& a, int nwg, hipStream_t s) {
     const size_t lds = (size_t)NS * (64 * TM + 64 * TN) * 128;
     auto kern = a.mode == 1 ? gemm_stream_kernel<TM, TN, NS, 1> : gemm_stream_kernel<TM, TN, NS, 0>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return XMEM_ERR_LAUNCH;
-    }
+    if (xmem_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds) != XMEM_OK) return XMEM_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, a);
     return xmem_check_launch();
 }

@@ -21,11 +21,15 @@ def _on_network_device(fn):
     so a core whose network lives on cuda:1 must not enqueue on cuda:0's stream when the caller never called set_device."""
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
-        dev = getattr(self.network, 'device', None)
-        if dev is None or dev.type != 'cuda' or torch.cuda.current_device() == (dev.index if dev.index is not None else torch.cuda.current_device()):
-            return fn(self, *args, **kwargs)
-        with torch.cuda.device(dev):
-            return fn(self, *args, **kwargs)
+        # ONE host thread drives the kernels of a process at a time (un-scoped scratch and the precision mode are per process,
+        # ops.workspace): the whole call holds the driver lock - captured stages, graph replays and the eager readout between them alike -
+        # so that threads sharing a process take turns call by call instead of interleaving inside one.
+        with ops._DRIVER:
+            dev = getattr(self.network, 'device', None)
+            if dev is None or dev.type != 'cuda' or torch.cuda.current_device() == (dev.index if dev.index is not None else torch.cuda.current_device()):
+                return fn(self, *args, **kwargs)
+            with torch.cuda.device(dev):
+                return fn(self, *args, **kwargs)
     return wrapper
 
 

@@ -169,7 +169,10 @@ class precision:
         # the mode is a process-wide switch and un-scoped scratch is shared per device: ONE host thread may be inside a network stage
         # at a time (the reference's InferenceCore is single-threaded too).  A second thread entering concurrently is a
         # contract violation and fails loudly instead of silently flipping the other thread's arithmetic mode; the same thread
-        # may nest, and different threads may take turns.
+        # may nest, and different threads may take turns.  InferenceCore's public calls (step, prefetch_keys, put_*) hold the same
+        # lock for their WHOLE duration with a blocking acquire (inference_core._on_network_device), replays and eager readout
+        # included: threads that drive cores of one process are serialised call by call; only a thread that calls into `ops` /
+        # XMem stages directly while another is inside one trips this check.
         if not _DRIVER.acquire(blocking=False):
             raise RuntimeError('xmem2_amd.ops: another host thread is inside a network stage - one thread drives the kernels of a process at a '
                                'time (run one process per stream of videos, xmem2_amd.launch)')
@@ -496,15 +499,20 @@ def _conv2d_half(lib, x, cw, out, out_ld, res, relu_in, relu_out, in_ld, cin, pl
         raise RuntimeError(f'conv2d (half): weight expects Cin={cw.cin} (padded {cin_h}), got {cin}')
     if cin_h > ldin:
         raise RuntimeError(f'conv2d (half): the input buffer has {ldin} channels per pixel, the layer reads {cin_h} (pad to a multiple of 8)')
-    if in_ld is not None or cin != cin_h:
+    if in_ld is not None:
         # a channel SLICE of a wider buffer: the kernel reads cin_h (= Cin padded to 8) halfs from the slice start whatever `cin` says,
         # and only the zero WEIGHTS mask the tail - 0 x Inf/NaN from a neighbouring slice or an uninitialised tail would be NaN.
         # So a slice must be a whole number of 8-half groups and must end inside its pixel (include/xmem_hip.h, xmem_conv_desc.in_half).
+        # (A whole, zero-padded buffer - in_ld None - is not a slice: its padding channels are the caller's zeros.)
         if cin % 8 != 0:
             raise RuntimeError(f'conv2d (half): a channel slice must hold a multiple of 8 channels, got cin={cin} '
                                '(pad the slice and zero-fill the padding channels)')
-        if x.storage_offset() % ldin + cin_h > ldin:
-            raise RuntimeError(f'conv2d (half): the slice [{x.storage_offset() % ldin}, +{cin_h}) crosses the pixel stride {ldin}')
+        base = x._base
+        if base is not None and base.dim() == 4 and base.shape[3] == ldin and base.is_contiguous():
+            # offset of the slice inside its pixel, measured from the PARENT buffer (which may itself sit anywhere in a workspace)
+            inpix = (x.storage_offset() - base.storage_offset()) % ldin
+            if inpix + cin_h > ldin:
+                raise RuntimeError(f'conv2d (half): the slice [{inpix}, +{cin_h}) crosses the pixel stride {ldin}')
     Ho = (H + 2 * cw.pad - cw.kh) // cw.stride + 1
     Wo = (W + 2 * cw.pad - cw.kw) // cw.stride + 1
     odt = out_dtype if out_dtype is not None else (out.dtype if out is not None else torch.float16)
