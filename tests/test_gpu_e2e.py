@@ -378,31 +378,55 @@ def test_e2e_480p_three_objects_consolidation_vs_oracle(hip_net_mo, ref_net_mo):
         _noise_floor_gate(tag, g, phases[ph], frac_cap=max(1e-4, 1.5 * floor['mismatch'] / floor['pixels']), floor_deficit=worst)
 
 
-def test_e2e_480p_three_objects_bench_c3_stream_vs_oracle(hip_net_mo, ref_net_mo):
-    """The stream `bench.py --workload c3` itself (25 frames, one permanent frame, mem_every=5: five memory frames carry PREDICTED
-    masks back into the memory) under the noise-floor gate.  Round 5's bench print on this clip was 119 px / IoU 0.99848 against the
-    oracle's own 32 px / 0.99939 - outside the gate this test applies; it was only a bench print then."""
+def test_e2e_480p_three_objects_plain_checkpoint_noise_floor(hip_net, ref_net):
+    """The config-3 clip on the PLAIN synthetic checkpoint (when the clip moved to the 'multi_object' conditioning, the plain
+    checkpoint with 3 objects was no longer gated at all).  On it 45 % of the pixels are ties between objects and the reference's own
+    argmax is noise (its IoU against itself across thread counts ~0.998), so the gate is the round-4 one: the HIP path may deviate from
+    oracle(1 thread) by 1.5x what oracle(8 threads) does on the same frames, never below IoU 0.997."""
     import clip_util as U
-    clip = U.c3_bench_clip()
-    o1, p1, s1 = U.run_oracle(ref_net_mo, clip, 1)
-    o8, _, _ = U.run_oracle(ref_net_mo, clip, 8)
-    a, p, s = U.run_gpu(hip_net_mo, clip)
+    clip = U.c3_clip()
+    clip.name += '_plain_checkpoint'                     # (the oracle cache is keyed by clip name: other weights, other trajectory)
+    o1, _, s1 = U.run_oracle(ref_net, clip, 1)
+    o8, _, _ = U.run_oracle(ref_net, clip, 8)
+    a, _, s = U.run_gpu(hip_net, clip)
     assert s == s1, 'memory sizes differ from the oracle'
     gpu, floor = U.compare(a, o1, clip.labels), U.compare(o8, o1, clip.labels)
-    print(f'bench c3 stream ({len(a)} frames):\n   HIP    vs oracle(1 thr): {U.fmt(gpu)}\n   oracle(8 thr) vs (1 thr): {U.fmt(floor)}')
-    # at SURVEY 8(c)'s margin: where the oracle's own top-2 margin exceeds 2e-3 the GPU path may differ on no more pixels than 1.5x the oracle
-    # differs from itself there (+ a handful)
-    def at_margin(x):
-        n = 0
-        for i in range(len(x)):
-            t2 = torch.topk(p1[i], 2, dim=0).values
-            n += int(((x[i] != o1[i]) & ((t2[0] - t2[1]).numpy() > 2e-3)).sum())
-        return n
-    g_m, f_m = at_margin(a), at_margin(o8)
-    print(f'   at a top-2 margin > 2e-3 of oracle(1 thr): HIP {g_m} px, oracle(8 thr) {f_m} px')
-    _noise_floor_gate('bench c3 stream', gpu, floor, frac_cap=0.0)
-    assert min(gpu['iou']) >= 0.999, f"north_star: IoU >= 0.999 per object, got {gpu['iou']}"
-    assert g_m <= 1.5 * f_m + 8, f'argmax mismatch at the 2e-3 margin: HIP {g_m} px vs the oracle\'s own {f_m}'
+    print(f'480p x 3 objects, plain checkpoint:\n   HIP    vs oracle(1 thr): {U.fmt(gpu)}\n   oracle(8 thr) vs (1 thr): {U.fmt(floor)}')
+    _noise_floor_gate('480p x 3 objects, plain checkpoint', gpu, floor, frac_cap=1e-4)
+
+
+def test_e2e_480p_three_objects_bench_c3_stream_vs_float64_reference(hip_net_mo):
+    """The stream `bench.py --workload c3` itself (25 frames, one permanent frame, mem_every=5: five memory frames carry PREDICTED masks
+    back into the memory) against the REFERENCE EVALUATED IN FLOAT64 (tests/golden/make_c3_bench_goldens.py: the imported reference's own
+    code with every tensor a double - the exact answer of its algorithm on these frames).
+
+    Why float64: round 5's bench print on this clip (HIP vs the fp32 oracle: 119 px, IoU 0.99848; oracle at 8 threads vs 1 thread: 32 px)
+    read as a parity gap 3.7x outside "the reference's own noise".  It is the fp32 REFERENCE that forks there: against float64 the
+    reference's fp32 path is off by 48 px at frame 7 alone (max |dp| 1.5e-2; 76 px / IoU 0.99864 over the clip in the build container,
+    102 px / 0.99811 on an MI355X host), the HIP path by 0 at that frame and 47 over the clip (IoU >= 0.99902), whatever the convolution
+    form (profiles/r06_c3_bench_stream_margins.txt, r06_c3_parity_by_plan.txt).  The oracle at 8 vs 1 thread share most of their
+    arithmetic and fork together, so that pair under-states the noise of an fp32 evaluation of this feedback loop.
+    Gate: IoU >= 0.999 per object against float64 (north_star), and no further from the exact answer than 1.5x the reference's own fp32
+    path is - in argmax pixels overall and at a float64 top-2 margin > 2e-3."""
+    import clip_util as U
+    g = load_golden('c3_bench_stream')
+    clip = U.c3_bench_clip(int(g['steps']))
+    assert ast.literal_eval(str(g['config'])) == clip.cfg and tuple(g['shape']) == tuple(clip.frames.shape)
+    a, p, s = U.run_gpu(hip_net_mo, clip)
+    assert np.array_equal(np.array(s), g['sizes']), 'memory sizes differ from the reference'
+    A, R64, R32 = np.stack(a), g['argmax_f64'], g['argmax_f32_1thr']
+    clear = np.unpackbits(g['clear_2e3'])[:A.size].reshape(A.shape).astype(bool)
+    gpu, ref32 = U.compare(list(A), list(R64), clip.labels), U.compare(list(R32), list(R64), clip.labels)
+    g_m, r_m = int(((A != R64) & clear).sum()), int(((R32 != R64) & clear).sum())
+    pd = np.abs(np.stack([q[:, 4::8, 4::8].numpy() for q in p]) - g['prob_f64_ds8'])
+    print(f'bench c3 stream ({len(a)} frames) against the reference in float64:\n   HIP path               : {U.fmt(gpu)}; at a margin > 2e-3: {g_m} px; max |dp| {pd.max():.2e}\n'
+          f'   reference fp32 (1 thr) : {U.fmt(ref32)}; at a margin > 2e-3: {r_m} px; max |dp| {float(g["max_abs_dp_f32_vs_f64"].max()):.2e}\n'
+          f'   HIP vs reference fp32  : {U.fmt(U.compare(list(A), list(R32), clip.labels))}\n'
+          f'   per frame HIP != f64: {[(int((A[i] != R64[i]).sum())) for i in range(len(a))]}\n   per frame f32 != f64: {[(int((R32[i] != R64[i]).sum())) for i in range(len(a))]}')
+    assert min(gpu['iou']) >= 0.999, f"north_star: IoU >= 0.999 per object against the exact answer, got {gpu['iou']}"
+    assert gpu['mismatch'] <= 1.5 * ref32['mismatch'] + 8, f"argmax mismatch vs float64: HIP {gpu['mismatch']} px, the reference's fp32 path {ref32['mismatch']}"
+    assert g_m <= 1.5 * r_m + 8, f'argmax mismatch vs float64 at the 2e-3 margin: HIP {g_m} px, the reference\'s fp32 path {r_m}'
+    assert pd.max() <= 1.5 * float(g['max_abs_dp_f32_vs_f64'].max()) + 1e-3
 
 
 def test_e2e_240p_two_objects_noise_floor(hip_net, ref_net):

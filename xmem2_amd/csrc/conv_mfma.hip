@@ -455,12 +455,22 @@ __global__ void wino_input_kernel(const float* __restrict__ in, int ldin, int B,
             for (int j = 0; j < 4; ++j) {
                 const int iw = 2 * tx - 1 + j;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
                     v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * ldin + c4 * 4);
-                    if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
                 d[i][j] = v;
             }
+        }
+        // relu AFTER every load has been requested: a relu inside the load loop sits behind a (uniform) branch of its own, which
+        // makes each load wait for its predecessor's max - 16 / 36 serialised round trips (round 6: 17.3 -> 10 us at 30x54x512)
+        if (relu_in) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = d[i][j];
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    d[i][j] = v;
+                }
         }
         f32x4 u[4][4];
 #pragma unroll
@@ -495,6 +505,19 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
         const int tx = (int)(t % tw); size_t r = t / tw;
         const int ty = (int)(r % th);
         const int b = (int)(r / th);
+        // the residual values are requested FIRST, together with the M planes: fetched inside the store loop each one sits behind the
+        // bounds branches of its pixel and costs a round trip of its own (round 6: 13.4 -> ~9 us at 60x108x256 with a residual)
+        f32x4 rv[2][2];
+        if (res) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int oh = min(2 * ty + dy, Ho - 1), ow = min(2 * tx + dx, Wo - 1);      // clamped: never stored when outside
+                    const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
+                    rv[dy][dx] = *reinterpret_cast<const f32x4*>(res + (res_bcast ? (size_t)oh * Wo + ow : pix) * ldres + n4 * 4);
+                }
+        }
         f32x4 m[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -522,7 +545,7 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
                 if (ow >= Wo) continue;
                 const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
                 f32x4 v = y[dy][dx] * sc + sh;
-                if (res) v += *reinterpret_cast<const f32x4*>(res + (res_bcast ? (size_t)oh * Wo + ow : pix) * ldres + n4 * 4);
+                if (res) v += rv[dy][dx];
                 if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
             }
@@ -750,12 +773,20 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
             for (int j = 0; j < 6; ++j) {
                 const int iw = 4 * tx - 1 + j;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
                     v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + ih) * W + iw) * ldin + c4 * 4);
-                    if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                }
                 d[i][j] = v;
             }
+        }
+        if (relu_in) {                                 // after the loads, not between them (see wino_input_kernel)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    f32x4 v = d[i][j];
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    d[i][j] = v;
+                }
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {              // columns: d[:, j] <- B^T d[:, j]
@@ -790,6 +821,17 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         const int tx = (int)(t % tw); size_t r = t / tw;
         const int ty = (int)(r % th);
         const int b = (int)(r / th);
+        f32x4 rv[4][4];                            // residual values, requested before the M planes (see wino_output_kernel)
+        if (res) {
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) {
+                    const int oh = min(4 * ty + dy, Ho - 1), ow = min(4 * tx + dx, Wo - 1);      // clamped: never stored when outside
+                    const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
+                    rv[dy][dx] = *reinterpret_cast<const f32x4*>(res + (res_bcast ? (size_t)oh * Wo + ow : pix) * ldres + n4 * 4);
+                }
+        }
         f32x4 s[4][6];                             // A^T m, column by column
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -814,7 +856,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
                 if (ow >= Wo) continue;
                 const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
                 f32x4 v = y[dx] * scl + sh;
-                if (res) v += *reinterpret_cast<const f32x4*>(res + (res_bcast ? (size_t)oh * Wo + ow : pix) * ldres + n4 * 4);
+                if (res) v += rv[dy][dx];
                 if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
             }
@@ -1107,6 +1149,15 @@ int launch_stream_positions(const Plan& pl, const float* V, const float* U, floa
 }
 
 // the 1x1 fast path needs 32-bit byte offsets into both operands (per group)
+// Transform kernels are grid-stride over (tile, channel quad) items, one item per thread.  A 1/16-resolution layer has ~15 000 items:
+// as 256-thread workgroups that is ~60 workgroups on 60 of the 256 CUs, each bound by its own CU's load / store path (measured
+// 10-17 us for 12 MB).  Below 512 workgroups of 256 the items are dealt as 64-thread workgroups instead: four times the CUs.
+static inline void transform_grid(size_t items, int& blocks, int& threads) {
+    threads = items < (size_t)512 * 256 ? 64 : 256;
+    size_t b = (items + threads - 1) / threads;
+    blocks = (int)(b > 16384 ? 16384 : b);
+}
+
 static bool conv_is_one(const ConvArgs& a) {
     static const int off = getenv("XMEM_CONV_ONE") && getenv("XMEM_CONV_ONE")[0] == '0';
     if (off) return false;
@@ -1231,9 +1282,9 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         float* V = reinterpret_cast<float*>(workspace);
         float* Mt = V + (size_t)36 * P * d->Cin;
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        size_t tot = P * (d->Cin / 4);
-        int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(wino4_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
+        int blocks, threads;
+        transform_grid(P * (d->Cin / 4), blocks, threads);
+        hipLaunchKernelGGL(wino4_input_kernel, dim3(blocks), dim3(threads), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
                            d->relu_in, V, pl.split ? 1 : 0);
         ConvArgs g = a;
         g.in = V; g.w = pl.split ? reinterpret_cast<const float*>(d->w_winograd4_split) : d->w_winograd4;
@@ -1248,9 +1299,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         rc = (pl.bk == 64) ? (pl.generic ? launch_bk<64, true>(pl, g, s, 36) : launch_bk<64, false>(pl, g, s, 36))
                            : (pl.generic ? launch_bk<32, true>(pl, g, s, 36) : launch_bk<32, false>(pl, g, s, 36));
         if (rc != XMEM_OK) return rc;
-        tot = P * (d->Cout / 4);
-        blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(wino4_output_kernel, dim3(blocks), dim3(256), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
+        transform_grid(P * (d->Cout / 4), blocks, threads);
+        hipLaunchKernelGGL(wino4_output_kernel, dim3(blocks), dim3(threads), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
                            d->res, d->ldres, d->res_broadcast ? 1 : 0, d->relu_out, d->out, d->ldout);
         return xmem_check_launch();
     }
@@ -1296,9 +1346,9 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         float* V = reinterpret_cast<float*>(workspace);
         float* Mt = V + (size_t)16 * P * d->Cin;
         hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-        size_t tot = P * (d->Cin / 4);
-        int blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(256), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
+        int blocks, threads;
+        transform_grid(P * (d->Cin / 4), blocks, threads);
+        hipLaunchKernelGGL(wino_input_kernel, dim3(blocks), dim3(threads), 0, s, d->in, d->ldin, d->B, d->H, d->W, d->Cin, th, tw,
                            d->relu_in, V, pl.split ? 1 : 0);
         if (pl.fused) {
             WinoArgs wa;
@@ -1328,9 +1378,8 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         rc = (pl.bk == 64) ? (pl.generic ? launch_bk<64, true>(pl, g, s, 16) : launch_bk<64, false>(pl, g, s, 16))
                            : (pl.generic ? launch_bk<32, true>(pl, g, s, 16) : launch_bk<32, false>(pl, g, s, 16));
         if (rc != XMEM_OK) return rc;
-        tot = P * (d->Cout / 4);
-        blocks = (int)((tot + 255) / 256); if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(wino_output_kernel, dim3(blocks), dim3(256), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
+        transform_grid(P * (d->Cout / 4), blocks, threads);
+        hipLaunchKernelGGL(wino_output_kernel, dim3(blocks), dim3(threads), 0, s, Mt, d->B, Ho, Wo, d->Cout, th, tw, d->scale, d->shift,
                            d->res, d->ldres, d->res_broadcast ? 1 : 0, d->relu_out, d->out, d->ldout);
         return xmem_check_launch();
     }
