@@ -228,16 +228,19 @@ def run_gpu(args, device, rank, world):
 
     host_t = {'step': 0.0, 'hint': 0.0, 'fetch': 0.0, 'n': 0} if os.environ.get('XMEM_BENCH_HOST_TIMES') else None
 
-    def one_step(i):
+    def one_step(i, stop=None):
+        # `stop`: one past the last frame of the stream being driven.  A finite stream does not hint past its end (run_on_video does
+        # not either): the batch-4 key pass of frames nobody will step is 3.7 ms of side-stream work that the closing device sync
+        # would wait for - 6 % of a 20-frame timed region (round 6; invisible at 200 frames).
         if host_t is None:
             prob = core.step(frame(i), None, None)
-            if i % KB == 0:                          # first frame of its batch consumed: hint the next batch under it
+            if i % KB == 0 and (stop is None or i + KB < stop):   # first frame of its batch consumed: hint the next batch under it
                 hint(i + KB)
             return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
         t0 = time.perf_counter()
         prob = core.step(frame(i), None, None)
         t1 = time.perf_counter()
-        if i % KB == 0:
+        if i % KB == 0 and (stop is None or i + KB < stop):
             hint(i + KB)
         t2 = time.perf_counter()
         am = ops.argmax_u8(prob)
@@ -265,7 +268,7 @@ def run_gpu(args, device, rank, world):
     t0 = time.perf_counter()
     out_masks = []
     for i in range(args.steps):
-        out_masks += one_step(args.warmup + i)
+        out_masks += one_step(args.warmup + i, stop=args.warmup + args.steps)
     out_masks += [m for _, m in fetcher.drain()]      # every mask of the timed steps is on the host before the clock stops
     assert len(out_masks) == args.steps
     if args.traced_child:
@@ -288,6 +291,7 @@ def run_gpu(args, device, rank, world):
     skip_extra = bool(os.environ.get('XMEM_BENCH_SKIP_PASSES'))            # debugging aid: none of the instrumented passes
     if rank == 0 and not args.traced_child and not args.scale_only and not skip_extra:
         inst_frames = min(args.steps, 100)
+        hint((args.warmup + args.steps + KB - 1) // KB * KB)          # (the timed stream ended without a hint past its end: resume them)
         ops.EVENT_TAP = []
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()

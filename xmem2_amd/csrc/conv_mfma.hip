@@ -34,7 +34,21 @@ struct ConvArgs {
     int res_mod;                               // > 0: residual is one image broadcast over the batch (pixel index mod Ho*Wo)
     long in_gstride, w_gstride, out_gstride;   // blockIdx.y = group (the 16 Winograd tile positions), floats
     int a_presplit;                            // SPLIT kernels: the A operand already holds [hi4|lo4] groups (Winograd-domain V)
+    int dbg;                                   // tools builds only (-DXMEM_TOOLS, env XMEM_CONV_DBG): 1 = no epilogue stores, 2 = every M-tile loads
+                                               // tile 0's A rows (L2-resident operands); results are then wrong - they attribute time
 };
+#ifdef XMEM_TOOLS
+#define CDBG(bit) (p.dbg & (bit))
+// XMEM_CONV_DBG & 8: phase timestamps of every workgroup of the pointwise kernel (s_memtime, 100 MHz-class constant clock):
+// entry, first tiles requested, first tiles in LDS, k-loop done, stores issued; xmem_conv2d_nhwc prints their averages.
+#define CTRACE_MAX 16384
+__device__ unsigned long long g_conv_trace[CTRACE_MAX][6];
+#define CTRACE(slot) do { if (CDBG(8) && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < CTRACE_MAX) \
+    g_conv_trace[blockIdx.x][slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CDBG(bit) 0
+#define CTRACE(slot) do { } while (0)
+#endif
 
 // ---- SPLIT-OPERAND arithmetic (opt-in mode 'fp32x', never the default) ------------------------------------------------
 // An fp32 value x is carried as two halfs, x = hi + lo (+ O(2^-21 |x|)): hi = x rounded toward zero to fp16 (saturating:
@@ -86,6 +100,7 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
     const int lrow = tid / C4, c4 = tid % C4;
+    CTRACE(0);
 
     // XCD-aware tile order: consecutive tile ids (same M-tile, neighbouring N-tiles) stay on one XCD / L2.
     int bid = blockIdx.x;
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
     if (ONE) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int m = min(m0 + lrow + RPP * i, p.M - 1);
+            const int m = CDBG(2) ? min(lrow + RPP * i, p.M - 1) : min(m0 + lrow + RPP * i, p.M - 1);
             unsigned pix = (unsigned)m;
             if (p.stride != 1) {               // strided pointwise layer (ResNet downsample): input pixel of output pixel m
                 const int b = m / p.HoWo, rem = m - b * p.HoWo;
@@ -249,8 +264,11 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
                     const int o = (r & 3) + 8 * (r >> 2);
                     int t = mr + o;
                     if (p.res_mod) { if (wrap_ok) { if (t >= p.res_mod) t -= p.res_mod; } else t = (mb + o) % p.res_mod; }
-                    if (half_io) rve[i * TN + j][r] = (mb + o < p.M) ? (float)reinterpret_cast<const _Float16*>(p.res)[(size_t)t * p.ldres + n] : 0.f;
-                    else rve[i * TN + j][r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
+                    // unconditional loads from a clamped row (a predicated load is a branch, and behind a branch every load waits for
+                    // its predecessor: rows past M are fetched from row M - 1 and never stored)
+                    if (!p.res_mod) t = min(t, p.M - 1);
+                    if (half_io) rve[i * TN + j][r] = (float)reinterpret_cast<const _Float16*>(p.res)[(size_t)t * p.ldres + n];
+                    else rve[i * TN + j][r] = p.res[(size_t)t * p.ldres + n];
                 }
             }
         }
@@ -258,9 +276,11 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
 
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
+        CTRACE(1);
         store_tile(0);
     }
     __syncthreads();
+    CTRACE(2);
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = (kt - kt_begin) & 1;
@@ -319,6 +339,7 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
         __syncthreads();
     }
 
+    CTRACE(3);
     // epilogue: lane owns output channel n (col) and 16 pixels (rows) per 32x32 tile.  The store mode is uniform, so it is
     // decided once and each 32x32 block runs straight-line code: all residual loads of a block are issued together
     // (one memory round trip per block instead of one per element) before the fused scale / shift / add / relu and stores.
@@ -348,25 +369,50 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
                     const int o = (r & 3) + 8 * (r >> 2);
                     int t = mr + o;
                     if (p.res_mod) { if (wrap_ok) { if (t >= p.res_mod) t -= p.res_mod; } else t = (mb + o) % p.res_mod; }
-                    if (half_io) rv[r] = (mb + o < p.M) ? (float)reinterpret_cast<const _Float16*>(p.res)[(size_t)t * p.ldres + n] : 0.f;
-                    else rv[r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
+                    if (!p.res_mod) t = min(t, p.M - 1);          // clamped, unconditional (see the early request above)
+                    if (half_io) rv[r] = (float)reinterpret_cast<const _Float16*>(p.res)[(size_t)t * p.ldres + n];
+                    else rv[r] = p.res[(size_t)t * p.ldres + n];
                 }
             }
+            // TWO PHASES (round 6).  gfx9 counts loads AND stores in one in-order counter (vmcnt).  With the fused arithmetic and the store
+            // of an element in one loop body - behind the row-bounds branch of that element - the compiler cannot know, at the join after a
+            // skipped element, whether scale / shift / residual have arrived, and waits vmcnt(0) in EVERY body: each store then waits for the
+            // previous store to land - 16 serialised round trips, 9 000 of a 17 500-cycle workgroup at the 64 -> 256 pointwise layer
+            // (profiles/r06_pointwise_epilogue.txt).  Phase 1 consumes every loaded operand; phase 2 only stores registers.
+            float vout[16];
+            if (mode >= 2) {
+                const bool add_res = mode == 3, relu = p.relu_out != 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = (r & 3) + 8 * (r >> 2);
-                if (mb + o >= p.M) continue;
-                float v = acc[i][j][r];
-                if (mode >= 2) {
-                    v = v * sc + sh;
-                    if (mode == 3) v += rv[r];
-                    if (p.relu_out) v = fmaxf(v, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (add_res) v += rv[r];
+                    vout[r] = relu ? fmaxf(v, 0.f) : v;
                 }
-                if (half_io) orow_h[(long)o * ldo] = (_Float16)v;
-                else orow[(long)o * ldo] = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vout[r] = acc[i][j][r];
+            }
+            if (CDBG(1)) { if (vout[0] == 1.2345e-33f) orow[0] = vout[0]; continue; }
+            if (m0 + wm * 32 * TM + i * 32 + 32 <= p.M) {      // (wave-uniform) every row of the block exists: straight-line stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = (r & 3) + 8 * (r >> 2);
+                    if (half_io) orow_h[(long)o * ldo] = (_Float16)vout[r];
+                    else orow[(long)o * ldo] = vout[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = (r & 3) + 8 * (r >> 2);
+                    if (mb + o >= p.M) continue;
+                    if (half_io) orow_h[(long)o * ldo] = (_Float16)vout[r];
+                    else orow[(long)o * ldo] = vout[r];
+                }
             }
         }
     }
+    CTRACE(4);
+    if (CDBG(8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CTRACE(5); }
 }
 
 template <bool HALF_IO>
@@ -535,6 +581,17 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
         y[1][0] = s1[0] + s1[1] + s1[2]; y[1][1] = s1[1] - s1[2] - s1[3];
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + n4 * 4);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n4 * 4);
+        // two phases (see the epilogue of conv_mfma_kernel): every loaded operand is consumed before the first store, so no store waits
+        // for its predecessor (loads and stores share the in-order vmcnt counter; a wait inside a bounds branch is a vmcnt(0))
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                f32x4 v = y[dy][dx] * sc + sh;
+                if (res) v += rv[dy][dx];
+                if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                y[dy][dx] = v;
+            }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             const int oh = 2 * ty + dy;
@@ -544,10 +601,7 @@ __global__ void wino_output_kernel(const float* __restrict__ Mt, int B, int Ho, 
                 const int ow = 2 * tx + dx;
                 if (ow >= Wo) continue;
                 const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
-                f32x4 v = y[dy][dx] * sc + sh;
-                if (res) v += rv[dy][dx];
-                if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
+                *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = y[dy][dx];
             }
         }
     }
@@ -697,15 +751,22 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(WinoArgs p) {
                 if (m >= p.P) continue;
                 const int tx = m % p.tw; const int t2 = m / p.tw;
                 const int ty = t2 % p.th; const int b = t2 / p.th;
+                // two phases (see the epilogue of conv_mfma_kernel): residual values first (clamped addresses), then the four stores
+                float vv[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int oh = min(2 * ty + (o >> 1), p.Ho - 1), ow = min(2 * tx + (o & 1), p.Wo - 1);
+                    const size_t pix = ((size_t)b * p.Ho + oh) * p.Wo + ow;
+                    float v = y[o][i][j][r] * sc + sh;
+                    if (p.res) v += p.res[(p.res_bcast ? (size_t)oh * p.Wo + ow : pix) * p.ldres + n];
+                    vv[o] = p.relu_out ? fmaxf(v, 0.f) : v;
+                }
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const int oh = 2 * ty + (o >> 1), ow = 2 * tx + (o & 1);
                     if (oh >= p.Ho || ow >= p.Wo) continue;
                     const size_t pix = ((size_t)b * p.Ho + oh) * p.Wo + ow;
-                    float v = y[o][i][j][r] * sc + sh;
-                    if (p.res) v += p.res[(p.res_bcast ? (size_t)oh * p.Wo + ow : pix) * p.ldres + n];
-                    if (p.relu_out) v = fmaxf(v, 0.f);
-                    p.out[pix * p.ldout + n] = v;
+                    p.out[pix * p.ldout + n] = vv[o];
                 }
             }
         }
@@ -844,10 +905,22 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
         }
         const f32x4 scl = *reinterpret_cast<const f32x4*>(scale + n4 * 4);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + n4 * 4);
+        // two phases (see the epilogue of conv_mfma_kernel): the 16 outputs are finished in the residual registers first ...
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
             f32x4 y[4];
             wino4_at(s[dy], y);
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                f32x4 v = y[dx] * scl + sh;
+                if (res) v += rv[dy][dx];
+                if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                rv[dy][dx] = v;
+            }
+        }
+        // ... then stored: no store depends on a load any more, none waits for its predecessor
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
             const int oh = 4 * ty + dy;
             if (oh >= Ho) continue;
 #pragma unroll
@@ -855,10 +928,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
                 const int ow = 4 * tx + dx;
                 if (ow >= Wo) continue;
                 const size_t pix = ((size_t)b * Ho + oh) * Wo + ow;
-                f32x4 v = y[dx] * scl + sh;
-                if (res) v += rv[dy][dx];
-                if (relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = v;
+                *reinterpret_cast<f32x4*>(out + pix * ldout + n4 * 4) = rv[dy][dx];
             }
         }
     }
@@ -1273,6 +1343,10 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     a.nk = pl.nk; a.splitk = pl.splitk; a.kt_per_split = pl.kt_per_split;
     a.tiles_m = pl.bm ? cdiv(a.M, pl.bm) : 0; a.tiles_n = pl.bn ? cdiv(a.Cout, pl.bn) : 0;
     a.raw = 0; a.res_mod = d->res_broadcast ? Ho * Wo : 0; a.in_gstride = 0; a.w_gstride = 0; a.out_gstride = 0;
+    a.dbg = 0;
+#ifdef XMEM_TOOLS
+    { static const int dbg = getenv("XMEM_CONV_DBG") ? atoi(getenv("XMEM_CONV_DBG")) : 0; a.dbg = dbg; }
+#endif
     if (pl.wino && pl.wino4) {
         const int th = cdiv(Ho, 4), tw = cdiv(Wo, 4);
         const size_t P = (size_t)d->B * th * tw;
@@ -1408,6 +1482,22 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
     if (pl.bk == 64) rc = pl.generic ? launch_bk<64, true>(pl, a, s) : launch_bk<64, false>(pl, a, s);
     else rc = pl.generic ? launch_bk<32, true>(pl, a, s) : launch_bk<32, false>(pl, a, s);
     if (rc != XMEM_OK) return rc;
+#ifdef XMEM_TOOLS
+    if (a.dbg & 8) {
+        static int printed = 0;
+        (void)hipStreamSynchronize(s);
+        const int n = a.tiles_m * a.tiles_n < CTRACE_MAX ? a.tiles_m * a.tiles_n : CTRACE_MAX;
+        static unsigned long long h[CTRACE_MAX][6];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 6 * n);
+        if (printed++ % 16 == 4) {
+            double d[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0;
+            for (int i = 0; i < n; ++i) { for (int k = 1; k < 6; ++k) d[k] += (double)(h[i][k] - h[i][0]); if (h[i][0] < tmin) tmin = h[i][0]; if (h[i][5] > tmax) tmax = h[i][5]; }
+            fprintf(stderr, "[conv trace] %d workgroups: entry -> first tiles requested %.0f, in LDS %.0f, k-loop done %.0f, stores issued %.0f, stores landed %.0f ticks (mean); "
+                            "first entry -> last store landed %.0f ticks; ticks are s_memtime units (100 MHz = 10 ns on gfx950)\n", n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n,
+                    (double)(tmax - tmin));
+        }
+    }
+#endif
     if (pl.splitk > 1) {
         const size_t total = (size_t)a.M * a.Cout;
         int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;

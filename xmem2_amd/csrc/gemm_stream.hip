@@ -269,17 +269,22 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmStreamArgs p) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int o = (r & 3) + 8 * (r >> 2);
-                            const int t = p.res_mod ? (mb + o) % p.res_mod : mb + o;
-                            rv[r] = (mb + o < p.M) ? p.res[(size_t)t * p.ldres + n] : 0.f;
+                            const int t = p.res_mod ? (mb + o) % p.res_mod : min(mb + o, p.M - 1);     // clamped, unconditional load
+                            rv[r] = p.res[(size_t)t * p.ldres + n];
                         }
+                    }
+                    // two phases (csrc/conv_mfma.hip, epilogue): no store between the uses of loaded operands
+                    float vout[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] * sc + sh;
+                        if (p.res) v += rv[r];
+                        vout[r] = p.relu_out ? fmaxf(v, 0.f) : v;
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][j][r] * sc + sh;
-                        if (p.res) v += rv[r];
-                        if (p.relu_out) v = fmaxf(v, 0.f);
-                        if (mb + o < p.M) orow[(size_t)o * p.ldc] = v;
+                        if (mb + o < p.M) orow[(size_t)o * p.ldc] = vout[r];
                     }
                 }
             }
