@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out/v10
+timeout 1500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_network.py tests/test_gpu_fp16_loop.py -q -x > gpurun_out/v10/tests.out 2>&1; echo "tests rc=$?" > gpurun_out/v10/summary.txt
+tail -3 gpurun_out/v10/tests.out >> gpurun_out/v10/summary.txt
+for p in fp32 fp32 fp16 fp16 fp32x; do echo -n "b32 $p: " >> gpurun_out/v10/summary.txt
+  timeout 300 python bench.py --scale-only --steps 200 --precision $p 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['value'])" >> gpurun_out/v10/summary.txt; done
+cat gpurun_out/v10/summary.txt

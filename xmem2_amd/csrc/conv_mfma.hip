@@ -421,6 +421,7 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs p) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(e / p.Cout), n = (int)(e - (size_t)m * p.Cout);
         float v = 0.f;
+#pragma unroll 4                                       // the slabs' loads in flight together (same summation order)
         for (int z = 0; z < p.splitk; ++z) v += p.partial[(size_t)z * total + e];
         v = v * p.scale[n] + p.shift[n];
         const size_t ri = (size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres + n;

@@ -50,19 +50,25 @@ __global__ void maxpool3x3s2_kernel(const TI* __restrict__ in, TO* __restrict__ 
         const int ow = (int)(pix % Wo); pix /= Wo;
         const int oh = (int)(pix % Ho);
         const int b = (int)(pix / Ho);
-        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        // nine UNCONDITIONAL loads from clamped coordinates (a clamped tap repeats an in-range neighbour of the same window: the max
+        // is unchanged): a load behind a bounds branch waits for its predecessor - nine serialised round trips (round 6)
+        f32x4 v[3][3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-            const int ih = oh * 2 - 1 + dy;
-            if ((unsigned)ih >= (unsigned)H) continue;
+            const int ih = min(max(oh * 2 - 1 + dy, 0), H - 1);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int iw = ow * 2 - 1 + dx;
-                if ((unsigned)iw >= (unsigned)W) continue;
-                const f32x4 v = ld4(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                const int iw = min(max(ow * 2 - 1 + dx, 0), W - 1);
+                v[dy][dx] = ld4(in + (((size_t)b * H + ih) * W + iw) * C + c4 * 4);
             }
         }
+        f32x4 m = v[1][1];                          // the centre tap (2 oh, 2 ow) is always inside
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                m.x = fmaxf(m.x, v[dy][dx].x); m.y = fmaxf(m.y, v[dy][dx].y); m.z = fmaxf(m.z, v[dy][dx].z); m.w = fmaxf(m.w, v[dy][dx].w);
+            }
         st4(out + (((size_t)b * Ho + oh) * Wo + ow) * C + c4 * 4, m);
     }
 }
@@ -269,6 +275,7 @@ __device__ __forceinline__ void cbam_channel_scale(const float* __restrict__ par
         float acc0[8], acc1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { acc0[u] = 0.f; acc1[u] = 0.f; }
+#pragma unroll 4                                     // four iterations' weight loads (32) in flight together, not eight after eight
         for (int c = lane; c < C; c += 64) {
             const float p0 = pb[c], p1 = pb[C + c];
 #pragma unroll
@@ -290,6 +297,7 @@ __device__ __forceinline__ void cbam_channel_scale(const float* __restrict__ par
         float sa = 0.f, smx = 0.f;
         const float* wr = w2 + (size_t)c * Cr;
         if ((Cr & 3) == 0) {
+#pragma unroll 8
             for (int j = 0; j < Cr; j += 4) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wr + j);
                 sa += hid[j] * w.x; smx += hid[Cr + j] * w.x;
