@@ -442,6 +442,41 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
     const int b = m / p.HoWo, rem = m - b * p.HoWo;
     const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
     float acc = 0.f;
+    if (p.KH == 3 && p.KW == 3 && p.Cin <= 256) {
+        // 3x3 with one 256-channel chunk per lane group (the mask head: 256 -> 1): the nine taps' loads are requested TOGETHER, from
+        // clamped coordinates (a padding tap is selected to zero afterwards).  The general loop below fetches tap after tap behind
+        // its bounds branches - nine serialised round trips (round 6).  Same products, same order of additions.
+        const int c = lane * 4;
+        if (c < p.Cin) {
+            f32x4 xv[9], wv[9];
+            bool ok[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ih = oh * p.stride - p.pad + t / 3, iw = ow * p.stride - p.pad + t % 3;
+                ok[t] = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+                xv[t] = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + ihc) * p.W + iwc) * p.ldin + c);
+                wv[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.Cin + c);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (!ok[t]) continue;                  // (no memory operation below: skipping costs nothing)
+                if (HALF_IN) {
+                    const h16x8 xh = __builtin_bit_cast(h16x8, xv[t]), wh = __builtin_bit_cast(h16x8, wv[t]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float xe = (float)xh[e];
+                        if (p.relu_in) xe = fmaxf(xe, 0.f);
+                        acc = fmaf(xe, (float)wh[e], acc);
+                    }
+                } else {
+                    f32x4 x = xv[t];
+                    if (p.relu_in) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                    acc = fmaf(x.x, wv[t].x, acc); acc = fmaf(x.y, wv[t].y, acc); acc = fmaf(x.z, wv[t].z, acc); acc = fmaf(x.w, wv[t].w, acc);
+                }
+            }
+        }
+    } else
     for (int kh = 0; kh < p.KH; ++kh) {
         const int ih = oh * p.stride - p.pad + kh;
         if ((unsigned)ih >= (unsigned)p.H) continue;

@@ -230,6 +230,7 @@ __global__ void cbam_channel_pool_kernel(const T* __restrict__ g, float* __restr
     float s = 0.f, m = -INFINITY;
     if (c < C) {
         const T* gb = g + (size_t)b * P * C + c;
+#pragma unroll 8                                     // eight pixels' loads in flight together (same order of additions)
         for (int pidx = p0 + stripe; pidx < p1; pidx += 4) {
             const float v = (float)gb[(size_t)pidx * C];
             s += v; m = fmaxf(m, v);
@@ -357,18 +358,26 @@ __global__ __launch_bounds__(256) void cbam_gate_apply_kernel(const T* __restric
         float s = 0.f;
         if (pix < P) {
             const int y = pix / W, x = pix - y * W;
-            for (int t = l; t < 98; t += 16) {
+            // the lane's 6-7 taps: unconditional loads from clamped coordinates, requested together; a padding tap is selected away
+            float cv[7]; bool okv[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int t = min(l + 16 * u, 97);
                 const int ch = t / 49, r = t - ch * 49, dy = r / 7, dx = r - dy * 7;
                 const int iy = y + dy - 3, ix = x + dx - 3;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    s += comp[(((size_t)b * H + iy) * W + ix) * 2 + ch] * swl[t];
+                okv[u] = l + 16 * u < 98 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                cv[u] = comp[(((size_t)b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * 2 + ch];
             }
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (okv[u]) s += cv[u] * swl[min(l + 16 * u, 97)];
         }
         s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
         if (l == 0) sg[i] = sigmoidf_(s + sb[0]);
     }
     __syncthreads();
     const int C4 = C >> 2;
+#pragma unroll 4
     for (int e = tid; e < CBAM_PIX * C4; e += 256) {
         const int c4 = e % C4, i = e / C4;
         const int pix = blockIdx.x * CBAM_PIX + i;
