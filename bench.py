@@ -911,7 +911,9 @@ def main():
             'schema_note': 'schema 5 (round 5): roofline.frac = F_sim / mean duration of the filter kernel in the marker-cut trace / 2.5 PF (as round 4); '
                            'roofline.call_frac = F_sim / the whole select call (all its launches, trace) / 2.5 PF (new); conv_roofline.achieved/frac = '
                            'EXECUTED MFMA FLOPs / conv family time / the peak of the pipe the mode runs on (fp32: 157.3 TF; fp16 / fp32x / fp16w modes: 2.5 PF - '
-                           'round 4 divided every mode by 157.3); parity.clear_margin = 2e-2 (round 4: 5e-2) and parity.survey_margin = 2e-3',
+                           'round 4 divided every mode by 157.3); parity.clear_margin = 2e-2 (round 4: 5e-2) and parity.survey_margin = 2e-3.  Round 6, same schema: '
+                           'config.early_readout is true (the schedule is the default again: its wrong stream was a caller-side race, DESIGN.md 4.7); the timed '
+                           'stream does not hint frames past its end; cpu_baseline gains threads / host_physical_cores (cores = threads used)',
             'roofline': {'bound': 'mfma',
                          'kernel': 'affinity_filter16_kernel<false, 4|8> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
                                    'of model/memory_util.py:7-39 on v_mfma_f32_32x32x16_f16 with augmented fp16 operands (the result is a rigorous '

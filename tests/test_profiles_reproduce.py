@@ -1,5 +1,5 @@
 """The trace-derived figures of the committed B32 bench line must follow from the committed trace (VERDICT round 3, item 2:
-`roofline.frac` reproducible from `profiles/`): `profiles/r0N_bench_b32_timed_region_kernel_trace.csv` (round 4 and round 5) is the rocprofv3 kernel trace
+`roofline.frac` reproducible from `profiles/`): `profiles/r0N_bench_b32_timed_region_kernel_trace.csv` (rounds 4 - 6) is the rocprofv3 kernel trace
 of the line's traced child cut to its timed region; this test re-derives `roofline.achieved / frac` (mean and median), the
 conv-family time of `conv_roofline` and the family table from it with bench.py's own parser.  No GPU, no reference."""
 import json
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 PROF = os.path.join(ROOT, 'profiles')
 
 
-@pytest.mark.parametrize('rnd', ['r04', 'r05'])
+@pytest.mark.parametrize('rnd', ['r04', 'r05', 'r06'])
 def test_b32_roofline_follows_from_the_committed_trace(rnd):
     import bench
     LINE, TRACE = os.path.join(PROF, f'{rnd}_bench_b32.json'), os.path.join(PROF, f'{rnd}_bench_b32_timed_region_kernel_trace.csv')
@@ -46,7 +46,8 @@ def test_b32_roofline_follows_from_the_committed_trace(rnd):
         aff_us = tr['families']['affinity'][1] / frames / 1e3
         assert r['call_frac'] == pytest.approx(r['algorithmic_gflop_per_frame'] / (aff_us * 1e-3) / bench.PEAK_F16_MFMA_TFLOPS, rel=1e-6)
         assert line['schema'] == bench.SCHEMA and line['parity']['clear_margin'] == bench.CLEAR_MARGIN
-        assert line['config']['early_readout'] is False      # the headline does not use the opt-in schedule
+        # round 5: the headline did not use the (then opt-in, then unexplained) early readout; round 6: root cause found, default on
+        assert line['config']['early_readout'] is (rnd >= 'r06')
     # the per-frame table committed beside the trace is the same parse
     table = open(os.path.join(PROF, f'{rnd}_bench_b32_timed_region_per_frame.csv')).read()
     assert f'conv,{tr["families"]["conv"][0] / frames:.2f},{conv_us:.1f}' in table

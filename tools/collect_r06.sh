@@ -48,4 +48,8 @@ for sh in "$S1" "$S2" "$S3" "$S4" "$S5" "$S6" "$S7" "$S8" "$S9" "$S10"; do
   timeout 120 tools/conv_bench -n 30 "$sh" 3,9,19,23,26,24 >> $OUT/${R}_conv_bench_isolated_layers.txt 2>&1
 done
 fi
+if [ $PART = all ] || [ $PART = e ]; then
+# 7. run_on_video on files (decode + H2D + step + PNG masks; the reference harness's entry point, unchanged signature)
+timeout 600 python tools/video_e2e_probe.py 400 > $OUT/${R}_run_on_video_files.txt 2>&1
+fi
 ls -la $OUT
