@@ -336,7 +336,11 @@ def run_gpu(args, device, rank, world):
             mm = core.memory
             n_now = mm.temporary_work_mem.size + mm.permanent_work_mem.size + mm.long_mem.size
             if lib.xmem_affinity_debug_offsets(n_now, hw, *[C.byref(x) for x in offs]) == 0:
-                ws = ops.workspace(0, device, 'affinity')
+                # the scratch the LAST select of this frame ran on: with early readout (the default) that is the readout of the NEXT
+                # hinted frame, enqueued on the readout stream under its own scratch scope
+                early_scope = f'@early#{core._uid}#' if (getattr(core, 'early_readout', False) and core._early is not None) else ''
+                with ops.ws_scope(early_scope):
+                    ws = ops.workspace(0, device, 'affinity')
                 nt = (hw + 127) // 128
                 cnt = ws[offs[0].value:offs[0].value + 4 * hw].view(torch.int32).float()
                 fl = ws[offs[1].value:offs[1].value + 4 * nt].view(torch.int32)
@@ -921,7 +925,8 @@ def main():
                                    'frame\'s matches, scan of the bit matrix, [tighten + second filter / scan pass over query tiles whose lists '
                                    'overflowed], exact fp32 refine of the listed candidates - outputs bit-identical to the fp32 MFMA select',
                          'note': 'achieved = SURVEY 8(d) algorithmic FLOPs of the similarity (F_sim = 4*C_k*N*HW per call) / the average duration of '
-                                 'THIS kernel; peak = the dense fp16 MFMA peak, the pipe it runs on; frac = executed fraction of that pipe in algorithmic '
+                                 'THIS kernel (since round 6 it runs on the readout stream UNDER the previous frame\'s decoder - early readout is the '
+                                 'default -, so its in-stream duration includes sharing the chip: 35.7 us against 30-33 us when it ran alone in its step); peak = the dense fp16 MFMA peak, the pipe it runs on; frac = executed fraction of that pipe in algorithmic '
                                  'FLOPs (executed_tflops counts the K = 144 operands and the queries padded to 64).  frac_fp32_equivalent is the round-2 '
                                  'yardstick: F_sim / the time of the WHOLE call (all kernels) / the fp32 MFMA peak the contraction ran on before - it '
                                  'exceeds 1 on large memories because the work is not done in fp32 any more',
