@@ -44,8 +44,26 @@ def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref
             q = ref.step(clip[i], None, None, end=(i == steps - 1))
             rm = ref.memory
             traj.append((q.clone(), (rm.temporary_work_mem.size, rm.permanent_work_mem.size, rm.long_mem.size)))
-        _ORACLE['b32'] = (perm, traj)
-    ref_perm, ref_traj = _ORACLE['b32']
+        # the reference path's own noise on these frames at SURVEY 8(c)'s margin (gate the 2e-3 margin against the floor in a
+        # test, not only in bench.py's print): the same oracle again at another thread count
+        prev = torch.get_num_threads()
+        torch.set_num_threads(8 if prev != 8 else 4)
+        try:
+            ref2 = R.RefCore(ref_net, cfg)
+            ref2.set_all_labels([1])
+            for j in range(P):
+                ref2.put_to_permanent_memory(frames[j], masks[j])
+            floor_tight = floor_all = 0
+            for i in range(steps):
+                q2 = ref2.step(clip[i], None, None, end=(i == steps - 1))
+                q1 = traj[i][0]
+                t2 = torch.topk(q1, 2, dim=0).values
+                d = torch.argmax(q1, 0) != torch.argmax(q2, 0)
+                floor_all += int(d.sum()); floor_tight += int((d & ((t2[0] - t2[1]) > 2e-3)).sum())
+        finally:
+            torch.set_num_threads(prev)
+        _ORACLE['b32'] = (perm, traj, (floor_all, floor_tight))
+    ref_perm, ref_traj, (floor_all, floor_tight) = _ORACLE['b32']
     core = InferenceCore(hip_net, cfg)
     core.set_all_labels([1])
     for j in range(P):
@@ -53,7 +71,7 @@ def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref
     n_hw = (480 // 16) * (864 // 16)
     assert core.memory.permanent_work_mem.size == ref_perm == P * n_hw == 51840
     dev = [f.cuda() for f in clip]
-    ious, mism, clear_mism, hinted_calls, saw_lt = [], 0, 0, 0, None
+    ious, mism, clear_mism, tight_mism, hinted_calls, saw_lt = [], 0, 0, 0, 0, None
     calls = []
     orig = ops.affinity_topk
 
@@ -73,6 +91,7 @@ def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref
             mism += int((a != b).sum())
             top2 = torch.topk(q, 2, dim=0).values
             clear_mism += int(((a != b) & ((top2[0] - top2[1]).numpy() > 2e-2)).sum())
+            tight_mism += int(((a != b) & ((top2[0] - top2[1]).numpy() > 2e-3)).sum())
             m = core.memory
             assert (m.temporary_work_mem.size, m.permanent_work_mem.size, m.long_mem.size) == ref_sizes, f'step {i}: memory sizes differ'
             if saw_lt is None and m.long_mem.size > 0:
@@ -81,7 +100,8 @@ def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref
     finally:
         ops.affinity_topk = orig
     n_pix = steps * hw[0] * hw[1]
-    print(f'B32 stream: per-step IoU {["%.5f" % x for x in ious]}; argmax mismatch {mism}/{n_pix} (clear margin: {clear_mism}); '
+    print(f'B32 stream: per-step IoU {["%.5f" % x for x in ious]}; argmax mismatch {mism}/{n_pix} (at a margin > 2e-2: {clear_mism}, > 2e-3: {tight_mism}; '
+          f'the oracle against itself at another thread count: {floor_all}, > 2e-3: {floor_tight}); '
           f'consolidation at step {saw_lt}; affinity calls (N, hinted): {calls}')
     assert len(calls) == steps and all(h for _, h in calls[1:]), 'every call after the first must carry a hint'
     assert all(n >= 51840 for n, _ in calls), 'the memory never drops below the 32 permanent frames (filter path: >= 256 tiles)'
@@ -92,6 +112,8 @@ def test_b32_stream_with_cut_insertions_and_consolidation_vs_oracle(hip_net, ref
     # still agree (identical argmax at a clear margin, few flips overall)
     assert clear_mism == 0, f'{clear_mism} argmax differences where the oracle\'s top-2 margin exceeds 2e-2'
     assert mism / n_pix < 1e-4, f'argmax mismatch {mism}/{n_pix}'
+    # SURVEY 8(c)'s own margin: no more pixels than 1.5x what the reference differs from itself there (+ a handful)
+    assert tight_mism <= 1.5 * floor_tight + 8, f'argmax mismatch at the 2e-3 margin: {tight_mism} px vs the oracle\'s own {floor_tight}'
 
 
 @pytest.mark.parametrize('n_obj', [1, 2])
