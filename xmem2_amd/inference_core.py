@@ -70,11 +70,11 @@ class InferenceCore:
         # early readout: the memory readout of the NEXT prefetched frame (it needs that frame's key and the memory, not this frame's
         # decoder) is enqueued on a third stream as soon as this frame's own readout / memory insertion is done, and runs under this
         # frame's decoder.  Same kernels on the same operands; consumed by the next step() only if the memory is unchanged.
-        # OPT-IN (XMEM_EARLY_READOUT=1 or core.early_readout = True), off by default: it is bit-identical to the in-step order in every
-        # test (tests/test_gpu_stream_b32.py, test_gpu_c4_stream.py) and worth +4 % at B32, but `bench.py`'s parity leg caught ONE
-        # stream (the first stream of a second core on a shared network, preloaded with seconds of host work between the calls) whose
-        # masks were wrong from its first frame on some boxes and right on others, while the same stream repeated in the same process -
-        # with and without early readout - was right (profiles/r05_early_readout_ab.txt).  Not understood, so not the default.
+        # DEFAULT since round 6 (XMEM_EARLY_READOUT=0 or core.early_readout = False turns it off): bit-identical to the in-step order in every
+        # test (tests/test_gpu_stream_b32.py, test_gpu_c4_stream.py, test_gpu_c5_stream.py, test_gpu_prefetch_sync.py), +4 % at B32.  Round 5
+        # kept it opt-in because `bench.py`'s parity leg showed one wrong stream with it; that was a caller-side race of the leg itself -
+        # device inputs hinted before the stream that cloned them had finished (see prefetch_keys) - which the extra stream only made visible
+        # (profiles/r06_early_readout_root_cause.txt).
         self._ro_stream = None
         self._early = None
         self.early_readout = os.environ.get('XMEM_EARLY_READOUT', '1') != '0'
