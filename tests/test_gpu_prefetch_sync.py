@@ -162,3 +162,39 @@ def test_early_readout_is_retired_before_steps_and_edits_that_do_not_consume_it(
     assert s0 == s1 and torch.equal(h0, h1)
     for i, (a, b) in enumerate(zip(p0, p1)):
         assert torch.equal(a, b), f'step {i + 3}: probabilities differ (max {float((a - b).abs().max()):.2e})'
+
+
+def test_two_live_cores_hinting_on_one_network_keep_their_own_frames(hip_net):
+    """Two cores alive at once on one network (two videos interleaved by one host thread), both hinting batches of the same size:
+    the key-stage buffer groups belong to a core's owner token, so core B's hint never lands in the group that still holds core A's
+    unconsumed frames.  Each core's masks equal the ones it computes alone - bit for bit - and neither had to drop a hint."""
+    from xmem2_amd.inference_core import InferenceCore
+    from xmem2_amd.synth import synthetic_frames, synthetic_masks
+    hw, t, kb = (240, 432), 13, 4
+    fa = T(synthetic_frames(t, *hw, seed=3)).cuda(); ma = T(synthetic_masks(t, 1, *hw)).cuda()
+    fb = T(synthetic_frames(t, *hw, seed=4)).cuda(); mb = ma.flip(-1).contiguous()
+    cfg = _cfg(mem_every=10 ** 9)
+    torch.cuda.synchronize()
+    solo_a, _ = _stream(hip_net, cfg, [(fa[0], ma[0])], [fa[i] for i in range(1, t)], 1, lambda fs: list(fs), inputs_complete=True)
+    solo_b, _ = _stream(hip_net, cfg, [(fb[0], mb[0])], [fb[i] for i in range(1, t)], 1, lambda fs: list(fs), inputs_complete=True)
+
+    cores = []
+    for f, m in ((fa, ma), (fb, mb)):
+        c = InferenceCore(hip_net, cfg)
+        c.set_all_labels([1])
+        c.put_to_permanent_memory(f[0], m[0])
+        cores.append(c)
+    assert cores[0]._uid != cores[1]._uid
+    outs = ([], [])
+    for a in range(1, t, kb):
+        for c, f in zip(cores, (fa, fb)):                                # both hint before either consumes
+            c.prefetch_keys([f[i] for i in range(a, min(a + kb, t))], inputs_complete=True)
+        for i in range(a, min(a + kb, t)):                               # ... and consume frame by frame, alternating
+            for k, (c, f) in enumerate(zip(cores, (fa, fb))):
+                assert any(e['ptr'] == f[i].data_ptr() for e in c._pfq), f'core {k} lost its hint of frame {i}'
+                outs[k].append(c.step(f[i], None, None).clone())
+    for k, solo in enumerate((solo_a, solo_b)):
+        for i, (x, y) in enumerate(zip(solo, outs[k])):
+            assert torch.equal(x, y), f'core {k} frame {i + 1}: {int((x.argmax(0) != y.argmax(0)).sum())} argmax pixels differ from its solo stream'
+    for c in cores:
+        c.cancel_prefetch()

@@ -194,7 +194,9 @@ class InferenceCore:
             self._side.wait_stream(main)                         # producers of the inputs on the caller's stream
         B = len(images)
         par = self._group_parity.get(B, 1) ^ 1                   # two buffer groups per batch size, used alternately
-        gid = ('g', B, par)
+        # (the group - a key-stage graph and its static buffers - belongs to THIS core's owner token: two live cores hinting on one
+        # network never overwrite each other's unconsumed frames; a recycled token takes over the dead core's captured stages)
+        gid = ('g', B, par, self._uid)
         if any(e['gid'] == gid for e in self._pfq):              # unconsumed frames still live there: give them up
             self._drop_prefetch()
         self._group_parity[B] = par
