@@ -281,8 +281,9 @@ def test_affinity_workspace_layout_is_consistent():
         assert cnt % 256 == 0 and flag % 256 == 0 and bound % 256 == 0
         assert cnt + 4 * hw <= total and bound + 4 * hw <= total and flag + 8 * ((hw + 127) // 128) <= total
         rows16 = (n + 32) * 144 * 2                                    # fp16 operand rows of the filter
-        bits = ((hw + 127) // 128) * 4 * ((n + 31) // 32) * 128      # one candidate bit per (row, query), 32-row x 32-query words
-        assert total >= rows16 + bits
+        lists = hw * 4 * (16384 if n >= 4096 * 64 else 4 * max(2048, 1 << max(0, (n // 64 - 1)).bit_length()))   # candidate index lists
+        assert total >= rows16 + lists
+        assert total < rows16 + lists + (1 << 28) + 64 * hw * 129 * 8  # (round 6) no N x HW / 8 bit matrix any more: 4.3 GB at config 5
         sizes.append(total)
     assert sizes[0] < sizes[1] < sizes[2]
     assert lib.xmem_affinity_topk_workspace_bytes(0, 1620, 30) == 0

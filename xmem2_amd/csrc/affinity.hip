@@ -737,6 +737,7 @@ struct HintArgs {
     float* tau0; int* gcnt; int* ovf;
     _Float16* qop16; float* qmeta;       // optional: query operands of the fp16 filter (affinity_filter.hip)
     int* flag1; int* flag2;              // optional: per-128-query-tile flags of the two filter passes, zeroed here
+    int* fcnt;                           // optional: the filter's list counters [HW][F16_CS], zeroed here
 };
 #define HINT_MAXC 320       // 5 queries x 64 indices
 #define HINT_NB 12          // entries taken from each grid neighbour's list
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(256) void affinity_hint_bound_kernel(HintArgs p) {
     if (lane == 0) {
         p.gcnt[q] = 0; if ((q & 63) == 0) p.ovf[q >> 6] = 0;
         if (p.flag1 && (q & 127) == 0) { p.flag1[q >> 7] = 0; p.flag2[q >> 7] = 0; }
+        if (p.fcnt) p.fcnt[(size_t)q * F16_CS] = 0;
     }
     // candidate lists: this query and its grid neighbours in the hint
     int nq[5]; int nn = 0;
@@ -1093,7 +1095,7 @@ inline bool aff_use_filter16() {
     return !(e && e[0] == '0');
 }
 
-struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, mask_off, rows16_off, gcand32_off, flag_off, total; int fsplits; };
+struct WsLayout { size_t key_off, cnt_off, bound_off, tau_off, ovf_off, gcand_off, gcnt_off, spill_off, qop16_off, qmeta_off, rows16_off, gcand32_off, flag_off, fcnt_off, total; int fsplits; };
 // fallback (MODE 3) split count: efficiency is irrelevant on this rare path, its worst-case global candidate buffers are not
 #define AFF_FB_GRID 128     // persistent workgroups of the safe fallback pass (a scene cut flags every tile: ~0.7 ms at B32)
 inline int fallback_splits(int HW) { (void)HW; return 16; }
@@ -1110,13 +1112,13 @@ WsLayout ws_layout(int HW, int n_total) {
     w.spill_off = w.gcnt_off + align_up((size_t)HW * sizeof(int), 256);
     // fallback buffers: one per persistent workgroup, cap = 96 + 128
     w.qop16_off = w.spill_off + align_up((size_t)AFF_FB_GRID * AFF_BQ * (96 + AFF_STEP_ROWS) * sizeof(u64), 256);
-    // fp16 filter: query operands, per-query meta, candidate bit matrix
+    // fp16 filter: query operands, per-query meta, operand rows of segments whose caller keeps none, candidate lists, flags
     w.qmeta_off = w.qop16_off + align_up((size_t)HW * F16_K * sizeof(_Float16), 256);
-    w.mask_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
-    w.rows16_off = w.mask_off + align_up(aff_filter16_mask_bytes(n_total, HW), 256);
+    w.rows16_off = w.qmeta_off + align_up((size_t)HW * 4 * sizeof(float), 256);
     w.gcand32_off = w.rows16_off + align_up(aff_filter16_rows_bytes(n_total), 256);
     w.flag_off = w.gcand32_off + align_up((size_t)HW * aff_filter16_list_stride(n_total) * sizeof(int), 256);
-    w.total = w.flag_off + align_up((size_t)2 * cdiv(HW, AFW_BQ) * sizeof(int), 256);
+    w.fcnt_off = w.flag_off + align_up((size_t)2 * cdiv(HW, AFW_BQ) * sizeof(int), 256);
+    w.total = w.fcnt_off + align_up((size_t)HW * F16_CS * sizeof(int), 256);
     return w;
 }
 }  // namespace
@@ -1228,6 +1230,7 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
         h.qmeta = use16 ? reinterpret_cast<float*>(ws + wl.qmeta_off) : nullptr;
         h.flag1 = use16 ? reinterpret_cast<int*>(ws + wl.flag_off) : nullptr;
         h.flag2 = use16 ? h.flag1 + cdiv(HW, AFW_BQ) : nullptr;
+        h.fcnt = use16 ? reinterpret_cast<int*>(ws + wl.fcnt_off) : nullptr;
         hipLaunchKernelGGL(affinity_hint_bound_kernel, dim3(cdiv(HW, 4)), dim3(256), 0, s, h);
         if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
         if (use16) {
@@ -1236,9 +1239,9 @@ extern "C" int xmem_affinity_topk_hinted(const xmem_key_segment* segs, int n_seg
             for (int i = 0; i < XMEM_MAX_SEGMENTS; ++i) f.seg[i] = a.seg[i];
             f.n_seg = ns; f.total_tiles = tiles; f.qk = qk; f.qe = qe; f.HW = HW; f.top_k = top_k;
             f.splits = 0; f.tiles_per_split = 0;
-            f.qop16 = h.qop16; f.qmeta = h.qmeta; f.mask = reinterpret_cast<u64*>(ws + wl.mask_off);
+            f.qop16 = h.qop16; f.qmeta = h.qmeta;
             f.rows16 = reinterpret_cast<_Float16*>(ws + wl.rows16_off);
-            f.tau = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = gcnt; f.lcap = aff_filter16_list_cap(base);
+            f.tau = tau0; f.gcand32 = reinterpret_cast<int*>(ws + wl.gcand32_off); f.gcnt = h.fcnt; f.cnt_diag = gcnt; f.lcap = aff_filter16_list_cap(base);
             f.lcap1 = f.lcap; f.lstride = aff_filter16_list_stride(base);
             f.flag1 = h.flag1; f.flag2 = h.flag2; f.only = nullptr; f.flag_out = nullptr;
             f.out_w = out_w; f.out_idx = out_idx; f.out_sim = out_sim;

@@ -59,6 +59,7 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 //   kA = (KAPPA ||x^2|| |msr|)^, kB = (KAPPA ||x|| |msr|)^, C = ||e||, D = ||2ke||, mq = ACC |b_sq| + ABS (C + D),
 //   zA = (ABS (||x^2|| + ||x||) |msr| 2^10)^ or +inf when the row leaves the fp16 range;  ^ = rounded up to fp16.
 // The fp32-accumulated dot product of the two is a(n,q) + eps(n,q): an UPPER bound of the exact similarity (see the file header).
+#define F16_CS 32              // ints between two queries' list counters (one 128-byte line each)
 #define F16_K 144              // halfs per operand row (288 B)
 #ifndef F16_KAPPA
 #define F16_KAPPA 1.07e-3f     // 2^-10 * 1.05 (two fp16 roundings per product) + 4.5e-5 (fp32 accumulation of filter and refine)
@@ -78,8 +79,10 @@ struct Filter16Args {
     const float* qmeta;              // [HW][4]   b_sq (select kernels' arithmetic), 0, 0, 0   }
     _Float16* rows16;                // workspace [N + 32][F16_K] for segments whose caller keeps no operand rows (seg[i].rows16 == 0 on entry)
     float* tau;                      // [HW] valid lower bound of the exact k-th similarity (-inf: none yet); raised by the tighten pass
-    u64* mask;                       // [query blocks of 32][total_tiles][16] candidate bits
-    int* gcand32; int* gcnt;         // [HW][lstride] candidate indices, [HW] list lengths zeroed by the bound kernel
+    int* gcand32; int* gcnt;         // [HW][lstride] candidate indices; [HW][F16_CS] list lengths (one counter per 128-byte line: the filter's
+                                     // drains bump them with atomics from every workgroup at once - 1620 counters in 51 lines serialise in a few
+                                     // L2 channels), zeroed by the bound kernel
+    int* cnt_diag;                   // [HW] final list lengths, written by the refine (diagnostics only)
     int lcap;                        // capacity of a list in THIS pass (pass 1: aff_filter16_list_cap; pass 2: lstride = up to 4x that -
                                      // after a scene cut the similarities are flat and thousands of pairs sit within eps of the k-th)
     int lcap1, lstride;              // pass-1 capacity; allocation stride = pass-2 capacity (aff_filter16_list_stride)
@@ -88,12 +91,11 @@ struct Filter16Args {
     // bound (k-th best EXACT similarity of the listed elements), pass 2 (only == flag1) filters and lists those tiles again.
     // A list that still overflows (exact ties by the thousand) sets flag2: the refine scans that query's tile in full.
     int* flag1; int* flag2;          // [ceil(HW/128)] each, zeroed by the bound kernel
-    const int* only;                 // filter / scan / tighten: restrict to tiles whose flag is set (nullptr: all tiles)
-    int* flag_out;                   // scan: where an overflow is recorded (flag1 in pass 1, flag2 in pass 2)
+    const int* only;                 // filter / tighten: restrict to tiles whose flag is set (nullptr: all tiles)
+    int* flag_out;                   // filter: where an overflow is recorded (flag1 in pass 1, flag2 in pass 2)
     float* out_w; int* out_idx; float* out_sim;
 };
-size_t aff_filter16_mask_bytes(int n_total, int HW);
 size_t aff_filter16_rows_bytes(int n_total);
 int aff_filter16_list_cap(int n_total);
 int aff_filter16_list_stride(int n_total);
-int aff_filter16_launch(Filter16Args a, void* stream);            // rows, filter, scan, tighten, filter, scan, refine
+int aff_filter16_launch(Filter16Args a, void* stream);            // rows, filter (lists), tighten, filter, refine

@@ -16,9 +16,12 @@
 //          of a memory row and a query row equal to  a(n,q) + eps(n,q)  DIRECTLY (b_sq split hi/lo, eps as products of row and
 //          query factors): the contraction yields an upper estimate of S, the epilogue is one compare.
 // filter:  tau(q) <= exact k-th similarity (the hint bound)  =>  every element of the exact top-k has a + eps >= tau.
-//          One bit per (memory row, query) pair says so; no lists, no atomics, no synchronisation.
-// scan:    the bit matrix (N x HW / 8 bytes, ~0.2 % set) becomes one index list per query.  A list that overflows (no usable
-//          bound: scene cut, garbage hint, hostile ties) flags its 128-query tile.
+//          One bit per (memory row, query) pair says so.  The bits never leave the chip (round 6; rounds 2-5 stored an N x HW / 8
+//          byte bit matrix and a scan kernel turned it into lists): a lane's NON-ZERO halfword of 16 pair bits (~3 % of them at
+//          the ~0.2 % pair density of a video) is pushed into a small per-WAVE LDS buffer - ballot + popcount + one ds_write, no
+//          atomics, nothing waited for - and the buffer is drained into the per-query index lists with ONE global atomic per
+//          halfword when it fills up and at the wave's end.  A list that overflows (no usable bound: scene cut, garbage hint,
+//          hostile ties) flags its 128-query tile.
 // refine:  the listed candidates (~100 per query) are re-evaluated EXACTLY in fp32 with the fmaf chain the fp32 MFMA select
 //          executes (bit-identical values), ranked, and soft-maxed as the merge kernel does: outputs bit-identical to the fp32
 //          path's.  Flagged tiles are computed by the fp32 select + merge of the same launch (affinity.hip), not here.
@@ -38,6 +41,9 @@
 #define F16_PF 2               // k-steps the row fragments are requested from LDS ahead of their MFMAs
 #endif
 #define F16_LDB 304            // bytes per memory operand row in LDS (288 + 16: odd multiple of 16 B, conflict-free 16-byte fragment reads)
+#define F16_WB 256             // entries of a wave's candidate buffer: the 16 PAD bytes of 64 of the staged operand rows (no LDS of its own:
+                               // 76 KB per 4-wave workgroup as before - with 4 KB more the second workgroup of a CU no longer fits: 61 us instead of 35)
+#define F16_WB_TSPAN 500       // an entry carries its tile relative to the buffer's base tile in 9 bits: drained at least every 500 tiles
 
 // the exact similarity of ONE (row, query) pair: the fmaf chain of the fp32 MFMA select (affinity_wide_kernel):
 // accumulator starts at -b_sq; per 8-channel group t and j = 0..3: k-pairs (8t+j, 8t+4+j) of [x^2 * -e] then of [x * 2ke].
@@ -159,10 +165,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
 
     h16x8 bq[NQB][9];
     float my_tau[NQB];
+    unsigned qopen[NQB];                                         // all ones, or 0 once this lane's query of block i takes no (more) candidates
 #pragma unroll
     for (int i = 0; i < NQB; ++i) {
         const int q = (b0 + i) * 32 + l31;
         const bool ok = active && q < p.HW;
+        qopen[i] = ok ? 0xffffffffu : 0u;                        // (a padding query's estimate is NaN beside a non-finite row: never listed)
         const _Float16* src = p.qop16 + (size_t)min(q, p.HW - 1) * F16_K + lh * 8;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -247,7 +255,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
 #pragma unroll
     for (int a = 0; a < NQB; ++a) bits[a] = 0u;
     h16x8 fr[9];
-    unsigned short* const mask16 = reinterpret_cast<unsigned short*>(p.mask);
+    // ---- candidates: bits -> per-wave LDS buffer -> per-query global lists --------------------------------------------------
+    // entry = halfword of 16 pair bits | filter lane << 16 | query block << 22 | (tile - tbase) << 23.  The buffer belongs to ONE wave:
+    // its fill count is a scalar, a push is a ballot, a prefix count and an LDS write that nothing waits for.  drain(): one lane per
+    // entry, ONE atomic reserves the halfword's slots in its query's list (bit 15 - r of lane l <-> row 32 (t - tile0) + (r & 3) +
+    // 8 (r >> 2) + 4 (l >> 5), query 32 b + (l & 31)); afterwards every lane looks at its own queries' counters: a list that is full
+    // (after a scene cut nearly every bit is set) takes no more pushes, so a hopeless pass costs lcap entries per query, not N.
+    // The buffer lives in the PAD of the staged rows: bytes 288 .. 303 of a 304-byte LDS row are neither written by the stash nor read
+    // by the fragment loads; entry j of wave w is dword j & 3 of the pad of row 64 w + (j >> 2) (rows of both stages, numbered through).
+    unsigned char* const wb = &Ah[0][0] + (size_t)wave * 64 * F16_LDB + 288;
+    auto wb_at = [&](int j) -> unsigned* {                       // (24-bit multiply-add: full rate; the 32-bit multiply is a quarter-rate instruction)
+        return reinterpret_cast<unsigned*>(wb + __umul24((unsigned)j >> 2, (unsigned)F16_LDB) + ((unsigned)j & 3u) * 4u);
+    };
+    int wcnt = 0, tbase = split * p.tiles_per_split;
+    auto drain = [&](int next_tile, bool last) {
+        if (DBG & 16) { wcnt = 0; tbase = next_tile; return; }   // tools: pushes only
+        for (int base = 0; base < wcnt; base += 64) {
+            const int i = base + lane;
+            if (i < wcnt) {
+                const unsigned e = *wb_at(i);
+                unsigned bm = e & 0xffffu;
+                const int fl = (int)(e >> 16) & 63, tile = tbase + (int)(e >> 23);
+                const int q = (b0 + (int)((e >> 22) & 1u)) * 32 + (fl & 31);
+                const SegDev sd = seg_of_tile(p, tile);
+                const int row0 = (tile - sd.tile0) * AFF_ROWS + 4 * (fl >> 5);
+                if (row0 + 28 > sd.n) {                          // the segment's clamped last tile: rows past its end are copies of its last row
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (row0 + (r & 3) + 8 * (r >> 2) >= sd.n) bm &= ~(0x8000u >> r);
+                }
+                const int n = __popc(bm);
+                if (n > 0) {
+                    int sl = (DBG & 32) ? 0 : atomicAdd(&p.gcnt[(size_t)q * F16_CS], n);   // (tools, 32: no atomics - every halfword lands on slot 0)
+                    if (sl + n >= p.lcap) p.flag_out[q >> 7] = 1; // a list that reaches its capacity counts as overflowed
+                    int* const dst = p.gcand32 + (size_t)q * p.lstride;
+                    while (bm) {
+                        const int r = __clz((int)bm) - 16;
+                        bm &= ~(0x8000u >> r);
+                        if (sl < p.lcap) dst[sl] = sd.base + row0 + (r & 3) + 8 * (r >> 2);
+                        ++sl;
+                    }
+                }
+            }
+        }
+        wcnt = 0; tbase = next_tile;
+        if (last) return;
+#pragma unroll
+        for (int i = 0; i < NQB; ++i) {
+            const int q = (b0 + i) * 32 + l31;
+            if (q < p.HW && __hip_atomic_load(&p.gcnt[(size_t)q * F16_CS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.lcap) qopen[i] = 0u;
+        }
+    };
     unsigned long long pmk0 = 0ull, pmk1 = 0ull;                 // lane masks of the two compares of the previous MFMA slot
     unsigned sink = 0u;                                          // (tools: knock-out 8 keeps the compares alive without the stores)
 
@@ -263,8 +321,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
             asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk0) : "s"(pmk0));                     \
             asm volatile("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[a_]), "=s"(junk1) : "s"(pmk1));                     \
             if ((DBG & 8) && e_ == 14) sink ^= bits[a_];                                                              \
-            else if (e_ == 14 && (PTOK) && (b0 + a_) * 32 < p.HW)                                                     \
-                mask16[(((size_t)(b0 + a_) * p.total_tiles + (PT)) << 6) + lane] = (unsigned short)bits[a_];          \
+            else if (e_ == 14 && (PTOK)) {                                                                            \
+                const bool nz_ = (bits[a_] & qopen[a_]) != 0u;                                                        \
+                const unsigned long long nm_ = __ballot(nz_);                                                         \
+                if (nz_) *wb_at(wcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(nm_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm_, 0u))) = \
+                    bits[a_] | ((unsigned)lane << 16) | ((unsigned)a_ << 22) | ((unsigned)((PT) - tbase) << 23);      \
+                wcnt += __popcll(nm_);                                                                                \
+            }                                                                                                         \
         }                                                                                                             \
         /* produce: two compares of the pending tile into two SGPR pairs of their own (nothing waits for them here) */     \
         if ((M) >= 1 && (M) < 1 + 8 * NQB) {                                                                          \
@@ -315,7 +378,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
             for (int g = 0; g < F16_STAGE; g += 2, ar += 2 * TILEB) {
                 // tile g into set A behind the compares of tile g - 1 (set B; for g = 0 the last tile of the previous stage),
                 // tile g + 1 into set B behind the compares of tile g
+                // (each tile pushes at most 128 entries - 64 lanes x 2 query blocks - of the tile before it)
+                if (wcnt > F16_WB - 128 || tile + g - tbase > F16_WB_TSPAN) drain(tile + g - 1, false);
                 F16P_TILE(cA, cB, ar, ar + TILEB, true, tile + g - 1, (s > 0 || g > 0) && tile + g - 1 < t_end)
+                if (wcnt > F16_WB - 128) drain(tile + g, false);
                 F16P_TILE(cB, cA, ar + TILEB, ar + 2 * TILEB, g + 2 < F16_STAGE, tile + g, tile + g < t_end)
             }
         }
@@ -326,11 +392,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
     }
     if (active) {                                                // the last tile's compares have no MFMAs to hide behind
         const int lt = t_begin + (nst - 1) * F16_STAGE + F16_STAGE - 1;
+        if (wcnt > F16_WB - 128) drain(lt, false);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
         for (int m = 1; m < 2 + 8 * NQB; ++m) { F16P_COMPARE(cB, m, lt, lt < t_end) }
+        drain(lt, true);
     }
-    if ((DBG & 8) && sink == 0x12345u) mask16[0] = (unsigned short)sink;
+    if ((DBG & 8) && sink == 0x12345u) p.cnt_diag[0] = (int)sink;
 #undef F16P_TILE
 #undef F16P_KSTEP
 #undef F16P_COMPARE
@@ -339,101 +407,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
 #undef F16_FETCH_ONE
 #undef F16_STASH
 #undef F16_STASH_ONE
-}
-
-// ============================================================ scan =====================================================
-// per (query block b, tile t): 64 halfwords, one per filter lane; bit 15 - r of lane l's halfword  <->  query 32 b + (l & 31),
-// row 32 (t - tile0) + (r & 3) + 8 (r >> 2) + 4 (l >> 5).  Read as 16 words of 64 bits: word k holds lanes 4k .. 4k + 3.
-#define SCAN_TILES 128
-#define SCAN_CAP 192
-template <bool PASS2>
-__global__ __launch_bounds__(256) void affinity_scan_kernel(Filter16Args p) {
-    __shared__ int s_cnt[32], s_base[32];
-    __shared__ int s_buf[32][SCAN_CAP];
-    __shared__ volatile int s_full[32];                          // the query's global list is full (or it is a padding query)
-    __shared__ int s_nfull;
-    __shared__ volatile int s_dead;                              // every list of this block is full: nothing more to collect
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    if (PASS2 && p.only[b >> 2] == 0) return;                    // pass 2: flagged query tiles only
-    const int t0 = blockIdx.y * SCAN_TILES;
-    const int nt = min(SCAN_TILES, p.total_tiles - t0);
-    if (tid == 0) { s_dead = 0; s_nfull = 0; }
-    __syncthreads();
-    if (tid < 32) {
-        // lists filled by workgroups that ran earlier need nothing from this one (after a scene cut nearly every bit is set:
-        // without these exits the scan would push hundreds of millions of candidates through atomics)
-        const int qg = b * 32 + tid;
-        const bool full = qg >= p.HW || p.gcnt[qg] >= p.lcap;
-        s_cnt[tid] = 0; s_full[tid] = full;
-        if (full && atomicAdd(&s_nfull, 1) == 31) s_dead = 1;
-    }
-    __syncthreads();
-    const u64* words = p.mask + ((size_t)b * p.total_tiles + t0) * 16;
-    const int lane = tid & 63;
-    auto insert = [&](int w, int j) {                            // bit j of word w (relative to this slice)
-        const int fl = 4 * (w & 15) + (j >> 4), r = 15 - (j & 15);  // filter lane, accumulator register
-        const int qi = fl & 31;
-        if (s_full[qi]) return;
-        const int tile = t0 + (w >> 4);
-        const SegDev sd = seg_of_tile(p, tile);
-        const int row = (tile - sd.tile0) * AFF_ROWS + (r & 3) + 8 * (r >> 2) + 4 * (fl >> 5);
-        if (row >= sd.n) return;                                 // clamped duplicate of the segment's last row
-        const int gi = sd.base + row;
-        const int slot = atomicAdd(&s_cnt[qi], 1);
-        if (slot < SCAN_CAP) s_buf[qi][slot] = gi;
-        else {                                                   // local buffer full: straight to the query's global list
-            const int qg = b * 32 + qi;
-            const int gs = atomicAdd(&p.gcnt[qg], 1);
-            if (gs < p.lcap) p.gcand32[(size_t)qg * p.lstride + gs] = gi;
-            if (gs + 1 >= p.lcap) {                              // a list that reaches its capacity counts as overflowed
-                p.flag_out[qg >> 7] = 1;
-                if (atomicExch(const_cast<int*>(&s_full[qi]), 1) == 0 && atomicAdd(&s_nfull, 1) == 31) s_dead = 1;   // counted once
-            }
-        }
-    };
-    for (int w0 = tid; w0 - lane < nt * 16; w0 += 4 * 256) {     // wave-uniform trip count
-        if (s_dead) break;                                       // (uniform per wave: one LDS word)
-        u64 m[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) m[u] = (w0 + 256 * u < nt * 16) ? words[w0 + 256 * u] : 0ull;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int w = w0 + 256 * u;
-            u64 mm = m[u];
-            // neighbouring queries and neighbouring rows share their good matches: set bits cluster.  A lane walks a sparse
-            // word itself; a dense word is taken apart by the whole wave, one bit per lane.
-            const bool dense = __popcll(mm) > 2;
-            unsigned long long dm = __ballot(dense);
-            if (!dense) {
-                while (mm) {
-                    const int j = __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    insert(w, j);
-                }
-            }
-            while (dm) {
-                const int src = __ffsll((long long)dm) - 1;
-                dm &= dm - 1;
-                const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)mm, src);
-                const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(mm >> 32), src);
-                const u64 wm = ((u64)hi << 32) | lo;
-                if ((wm >> lane) & 1ull) insert(w - lane + src, lane);
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < 32) {
-        const int n = min(s_cnt[tid], SCAN_CAP), qg = b * 32 + tid;
-        s_base[tid] = (n > 0 && qg < p.HW) ? atomicAdd(&p.gcnt[qg], n) : 0;
-        if (n > 0 && qg < p.HW && s_base[tid] + n >= p.lcap) p.flag_out[qg >> 7] = 1;      // list overflow (reaching the capacity counts)
-    }
-    __syncthreads();
-    for (int e = tid; e < 32 * SCAN_CAP; e += 256) {
-        const int qi = e / SCAN_CAP, j = e - qi * SCAN_CAP, qg = b * 32 + qi;
-        if (qg < p.HW && j < min(s_cnt[qi], SCAN_CAP) && s_base[qi] + j < p.lcap)
-            p.gcand32[(size_t)qg * p.lstride + s_base[qi] + j] = s_buf[qi][j];
-    }
 }
 
 // ============================================================ refine ===================================================
@@ -458,7 +431,8 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
     // a list that overflowed even with the tightened bound (thousands of exact ties): every memory element is evaluated
     // capacity of this query's list: a tile that went through the second pass lists up to lstride entries, the others lcap1
     const int cap = (!TIGHTEN && p.flag1[q >> 7] != 0) ? p.lstride : p.lcap1;
-    const bool full = !TIGHTEN && p.flag2[q >> 7] != 0 && p.gcnt[q] >= cap;
+    const int listed = p.gcnt[(size_t)q * F16_CS];
+    const bool full = !TIGHTEN && p.flag2[q >> 7] != 0 && listed >= cap;
     float* ne = s_op; float* ke2 = s_op + CK; u64* keys = s_keys[wv];
     if (wv == 0) {
         const float k = p.qk[(size_t)q * CK + lane];
@@ -466,7 +440,8 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
         ne[lane] = -e; ke2[lane] = 2.f * (k * e);
     }
     const float bs = p.qmeta[(size_t)q * 4];          // b_sq with the select kernels' arithmetic (bound kernel)
-    int total = min(p.gcnt[q], cap);
+    int total = min(listed, cap);
+    if (!TIGHTEN && threadIdx.x == 0) p.cnt_diag[q] = listed;      // diagnostics (xmem_affinity_debug_offsets): the list length as one dense array
     if (full) { total = 0; for (int i = 0; i < p.n_seg; ++i) total += p.seg[i].n; }
     const int* list = p.gcand32 + (size_t)q * p.lstride;
     // the first round's indices are requested without waiting for the count (the list is lcap >= 2048 long; stale entries are
@@ -580,7 +555,7 @@ __global__ __launch_bounds__(64 * RF_WAVES, RF_MINWG) void affinity_refine_kerne
     if (TIGHTEN) {
         if (lane == 0) {
             if (cnt >= p.top_k) p.tau[q] = fmaxf(p.tau[q], key_val(keys[p.top_k - 1]));
-            p.gcnt[q] = 0;
+            p.gcnt[(size_t)q * F16_CS] = 0;
         }
         return;
     }
@@ -614,11 +589,6 @@ int aff_filter16_list_stride(int n_total) {
 
 size_t aff_filter16_rows_bytes(int n_total) { return ((size_t)n_total + AFF_ROWS) * F16_K * sizeof(_Float16); }
 
-size_t aff_filter16_mask_bytes(int n_total, int HW) {
-    const size_t tiles = (size_t)cdiv(n_total, AFF_ROWS) + XMEM_MAX_SEGMENTS;
-    return (size_t)cdiv(HW, F16_BQ) * 4 * tiles * 16 * sizeof(u64);
-}
-
 // Measurement aid (bench.py): two HIP events the next hinted calls record right before / after their pass-1 filter launch, on the
 // launch stream.  NULL, NULL turns it off.  The pair belongs to the CALLING HOST THREAD (thread_local): calls issued by other threads,
 // on whatever stream or device, never see it - the library keeps no process-wide mutable state.  A tool's hook, not the data path.
@@ -644,7 +614,7 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     int nw = (a.HW >= 2048 && a.total_tiles >= 8192) ? 8 : 4;
     if (const char* e = getenv("XMEM_F16_WAVES")) nw = atoi(e) == 8 ? 8 : 4;   // tools: A/B
     const int wgq = 64 * nw, stage = nw, per_xcd = nw == 4 ? 32 * F16_WG_PER_CU : 32;
-    const int qt = cdiv(a.HW, wgq), qf = cdiv(a.HW, F16_BQ);
+    const int qt = cdiv(a.HW, wgq);
     // all workgroups of a split resident on one XCD at once when the query tiles allow: 8 x floor(per_xcd / query tiles) splits,
     // whole LDS stages, >= 2 stages per split
     int sp = 8 * (per_xcd / qt); if (sp < 8) sp = 8;
@@ -655,7 +625,7 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     int n_total = 0;
     for (int i = 0; i < a.n_seg; ++i) n_total += a.seg[i].n;
     a.qtiles = qt;
-    const dim3 fgrid(8 * qt * cdiv(a.splits, 8)), sgrid(qf * 4, cdiv(a.total_tiles, SCAN_TILES));
+    const dim3 fgrid(8 * qt * cdiv(a.splits, 8));
     int rc;
     // operand rows: kept by the caller (xmem_key_segment.rows16), else derived into the workspace for this call
     for (int i = 0; i < a.n_seg; ++i) {
@@ -670,23 +640,21 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     if (g_prof_ev[0]) (void)hipEventRecord(g_prof_ev[0], s);       // tools: bracket the pass-1 filter (xmem_affinity_profile_events)
 #ifdef XMEM_TOOLS
     // knock-outs of the pipelined kernel (wrong results, timing only): 1 no row fetch after the first stage, 4 no LDS stage
-    // hand-over (stash + barrier), 8 no bit-matrix stores
+    // hand-over (stash + barrier), 8 no candidate pushes, 16 pushes but no drain, 32 drain without atomics
     const int dbg = getenv("XMEM_F16_DBG") ? atoi(getenv("XMEM_F16_DBG")) : 0;
 #define F16P_DBG_CASE(D)                                                                                              \
     if (dbg == (D)) {                                                                                                 \
         if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<false, 8, D>), fgrid, dim3(512), 0, s, a);         \
         else hipLaunchKernelGGL((affinity_filter16_kernel<false, 4, D>), fgrid, dim3(256), 0, s, a);                 \
     } else
-    F16P_DBG_CASE(1) F16P_DBG_CASE(4) F16P_DBG_CASE(5) F16P_DBG_CASE(8) F16P_DBG_CASE(13)
+    F16P_DBG_CASE(1) F16P_DBG_CASE(4) F16P_DBG_CASE(5) F16P_DBG_CASE(8) F16P_DBG_CASE(13) F16P_DBG_CASE(16) F16P_DBG_CASE(32)
 #undef F16P_DBG_CASE
 #endif
     if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<false, 8>), fgrid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((affinity_filter16_kernel<false, 4>), fgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     if (g_prof_ev[1]) (void)hipEventRecord(g_prof_ev[1], s);
-    hipLaunchKernelGGL(affinity_scan_kernel<false>, sgrid, dim3(256), 0, s, a);
-    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    // pass 2: tiles with an overflowed list, with the bound their partial lists give (these three launches return at once
+    // pass 2: tiles with an overflowed list, with the bound their partial lists give (these two launches return at once
     // when nothing is flagged - the normal frame)
     a.only = a.flag1; a.flag_out = a.flag2;
     a.lcap = a.lstride;                                 // the second pass may list up to the allocation stride
@@ -694,8 +662,6 @@ int aff_filter16_launch(Filter16Args a, void* stream) {
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     if (nw == 8) hipLaunchKernelGGL((affinity_filter16_kernel<true, 8>), fgrid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((affinity_filter16_kernel<true, 4>), fgrid, dim3(256), 0, s, a);
-    if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
-    hipLaunchKernelGGL(affinity_scan_kernel<true>, sgrid, dim3(256), 0, s, a);
     if ((rc = xmem_check_launch()) != XMEM_OK) return rc;
     hipLaunchKernelGGL(affinity_refine_kernel<false>, dim3(a.HW), dim3(64 * RF_WAVES), 0, s, a);
     return xmem_check_launch();
