@@ -41,8 +41,9 @@
 #define F16_PF 2               // k-steps the row fragments are requested from LDS ahead of their MFMAs
 #endif
 #define F16_LDB 304            // bytes per memory operand row in LDS (288 + 16: odd multiple of 16 B, conflict-free 16-byte fragment reads)
-#define F16_WB 256             // entries of a wave's candidate buffer: the 16 PAD bytes of 64 of the staged operand rows (no LDS of its own:
+#define F16_WB 252             // entries of a wave's candidate buffer: the 16 PAD bytes of 63 of the staged operand rows (no LDS of its own:
                                // 76 KB per 4-wave workgroup as before - with 4 KB more the second workgroup of a CU no longer fits: 61 us instead of 35)
+#define F16_DU 4                // entries per lane and drain trip (F16_WB / 64: a full buffer goes in one trip)
 #define F16_WB_TSPAN 500       // an entry carries its tile relative to the buffer's base tile in 9 bits: drained at least every 500 tiles
 
 // the exact similarity of ONE (row, query) pair: the fmaf chain of the fp32 MFMA select (affinity_wide_kernel):
@@ -267,33 +268,56 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
     auto wb_at = [&](int j) -> unsigned* {                       // (24-bit multiply-add: full rate; the 32-bit multiply is a quarter-rate instruction)
         return reinterpret_cast<unsigned*>(wb + __umul24((unsigned)j >> 2, (unsigned)F16_LDB) + ((unsigned)j & 3u) * 4u);
     };
+    // pad of the wave's 64th row: the wave's "list is full" table, one bit per query of its two blocks (set by whichever lane's atomic
+    // finds a list at its capacity, read by the lane that owns the query after every drain)
+    unsigned* const wfull = reinterpret_cast<unsigned*>(wb + 63 * F16_LDB);
+    if (lane < NQB) wfull[lane] = 0u;
     int wcnt = 0, tbase = split * p.tiles_per_split;
     auto drain = [&](int next_tile, bool last) {
         if (DBG & 16) { wcnt = 0; tbase = next_tile; return; }   // tools: pushes only
-        for (int base = 0; base < wcnt; base += 64) {
-            const int i = base + lane;
-            if (i < wcnt) {
-                const unsigned e = *wb_at(i);
-                unsigned bm = e & 0xffffu;
+        // F16_DU entries per lane go through decode -> atomic -> stores TOGETHER: one memory round trip per drain, not one per 64
+        // entries.  A list found at its capacity closes its query for the whole wave (wfull): after a scene cut, or for a block of
+        // queries whose hint is garbage, nearly every bit is set and every split's wave would otherwise keep bumping the SAME counters
+        // (same-address atomics serialise in L2: 70 us instead of 36 with 128 such queries, profiles/r06_filter_lists.txt).
+        for (int base = 0; base < wcnt; base += 64 * F16_DU) {
+            unsigned bm[F16_DU]; int qq[F16_DU], g0[F16_DU], sl[F16_DU];
+#pragma unroll
+            for (int u = 0; u < F16_DU; ++u) {
+                const int i = base + 64 * u + lane;
+                const unsigned e = i < wcnt ? *wb_at(i) : 0u;
+                bm[u] = e & 0xffffu;
                 const int fl = (int)(e >> 16) & 63, tile = tbase + (int)(e >> 23);
-                const int q = (b0 + (int)((e >> 22) & 1u)) * 32 + (fl & 31);
+                qq[u] = (b0 + (int)((e >> 22) & 1u)) * 32 + (fl & 31);
                 const SegDev sd = seg_of_tile(p, tile);
                 const int row0 = (tile - sd.tile0) * AFF_ROWS + 4 * (fl >> 5);
                 if (row0 + 28 > sd.n) {                          // the segment's clamped last tile: rows past its end are copies of its last row
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (row0 + (r & 3) + 8 * (r >> 2) >= sd.n) bm &= ~(0x8000u >> r);
+                        if (row0 + (r & 3) + 8 * (r >> 2) >= sd.n) bm[u] &= ~(0x8000u >> r);
                 }
-                const int n = __popc(bm);
-                if (n > 0) {
-                    int sl = (DBG & 32) ? 0 : atomicAdd(&p.gcnt[(size_t)q * F16_CS], n);   // (tools, 32: no atomics - every halfword lands on slot 0)
-                    if (sl + n >= p.lcap) p.flag_out[q >> 7] = 1; // a list that reaches its capacity counts as overflowed
-                    int* const dst = p.gcand32 + (size_t)q * p.lstride;
-                    while (bm) {
-                        const int r = __clz((int)bm) - 16;
-                        bm &= ~(0x8000u >> r);
-                        if (sl < p.lcap) dst[sl] = sd.base + row0 + (r & 3) + 8 * (r >> 2);
-                        ++sl;
+                g0[u] = sd.base + row0;
+            }
+#pragma unroll
+            for (int u = 0; u < F16_DU; ++u) {
+                sl[u] = 0;                                       // (tools, 32: no atomics - every halfword lands on slot 0)
+                if (bm[u] != 0u && !(DBG & 32)) sl[u] = atomicAdd(&p.gcnt[(size_t)qq[u] * F16_CS], __popc(bm[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < F16_DU; ++u) {
+                if (bm[u] != 0u) {
+                    unsigned m = bm[u];
+                    int s_ = sl[u];
+                    if (s_ + __popc(m) >= p.lcap) {              // a list that reaches its capacity counts as overflowed
+                        p.flag_out[qq[u] >> 7] = 1;
+                        atomicOr(&wfull[(qq[u] >> 5) - b0], 1u << (qq[u] & 31));
+                        if (s_ >= p.lcap) m = 0u;
+                    }
+                    int* const dst = p.gcand32 + (size_t)qq[u] * p.lstride;
+                    while (m) {
+                        const int r = __clz((int)m) - 16;        // bit 15 - r
+                        m &= ~(0x8000u >> r);
+                        if (s_ < p.lcap) dst[s_] = g0[u] + (r & 3) + 8 * (r >> 2);
+                        ++s_;
                     }
                 }
             }
@@ -301,10 +325,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
         wcnt = 0; tbase = next_tile;
         if (last) return;
 #pragma unroll
-        for (int i = 0; i < NQB; ++i) {
-            const int q = (b0 + i) * 32 + l31;
-            if (q < p.HW && __hip_atomic_load(&p.gcnt[(size_t)q * F16_CS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.lcap) qopen[i] = 0u;
-        }
+        for (int i = 0; i < NQB; ++i)
+            if ((wfull[i] >> l31) & 1u) qopen[i] = 0u;
     };
     unsigned long long pmk0 = 0ull, pmk1 = 0ull;                 // lane masks of the two compares of the previous MFMA slot
     unsigned sink = 0u;                                          // (tools: knock-out 8 keeps the compares alive without the stores)
