@@ -242,6 +242,21 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
     // (profiles/r05_pointwise_prefetch_ab.txt).
     constexpr bool EARLY_SS = TM * TN == 2;
     float sce[EARLY_SS ? TN : 1], she[EARLY_SS ? TN : 1];
+    // Round 6: WHERE they are requested.  Until then they stood between a workgroup's entry and its first operand request (~770
+    // instructions with a per-element modulo behind a branch for the batch-broadcast case): the residual cost 13 us of a 51 us layer.  The
+    // plain case is now 16 clamped rows off ONE 64-bit base, and the requests are issued AFTER the first operand tiles are in LDS, right
+    // before the k-loop: they fly under the first k-tile's MFMAs, and the next tile's operand loads - younger - are waited for as a whole
+    // anyway.  (Between the first operand request and its wait they lose: the compiler's load counter is the minimum over all paths to
+    // a join, so with a path that loads no residual the operand wait becomes vmcnt(0..3), behind every younger residual load.)
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        CTRACE(1);
+        store_tile(0);
+    }
+
+    __syncthreads();
+    CTRACE(2);
+
     if (EARLY_SS) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -250,7 +265,25 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
             she[j] = mode >= 2 ? p.shift[n] : 0.f;
         }
     }
-    if (EARLY_RES && mode == 3) {
+    if (EARLY_RES && mode == 3 && p.res_mod == 0) {
+        // plain residual (the rule): 16 unconditional loads from clamped rows, no per-element modulo, no branch
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = min(n0 + wn * 32 * TN + j * 32 + l31, p.Cout - 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + wm * 32 * TM + i * 32 + 4 * lh;
+                const int left = p.M - 1 - mb;                             // rows below this lane's first one (negative past the end)
+                const long rb = (long)mb * p.ldres + n;                     // ONE 64-bit product per block; the rows are 24-bit multiples of ldres
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long t = rb + __mul24(min((r & 3) + 8 * (r >> 2), left), p.ldres);
+                    if (half_io) rve[i * TN + j][r] = (float)reinterpret_cast<const _Float16*>(p.res)[t];
+                    else rve[i * TN + j][r] = p.res[t];
+                }
+            }
+        }
+    } else if (EARLY_RES && mode == 3) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = min(n0 + wn * 32 * TN + j * 32 + l31, p.Cout - 1);
@@ -273,14 +306,6 @@ __global__ __launch_bounds__(64 * NW) void conv_mfma_kernel(ConvArgs p) {
             }
         }
     }
-
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        CTRACE(1);
-        store_tile(0);
-    }
-    __syncthreads();
-    CTRACE(2);
 
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = (kt - kt_begin) & 1;
