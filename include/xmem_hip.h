@@ -157,6 +157,13 @@ int xmem_area_downsample(const float* in, int ldin, float* out, int ldout, int B
  * MainToGroupDistributor (group_modules.py:55-82) and torch.cat([g, h], 2) (modules.py:59,89). */
 int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* dst, int lddst, int B, int P, int C, void* stream);
 
+/* The input of HiddenUpdater's three pointwise convolutions as one concatenated tensor, in one launch (model/modules.py:49-57:
+ * g16_conv(g[0]) + g8_conv(downsample_groups(g[1], 1/2)) + g4_conv(downsample_groups(g[2], 1/4)), g[2] = cat(g4, logits)):
+ * out [K][h][w][ldout] <- [ g16 [K][h][w][c16] | area2(g8 [K][2h][2w][c8]) | area4(g4 [K][4h][4w][c4]) | area4(logits [K][4h][4w][1]) ];
+ * channels past c16 + c8 + c4 + 1 are not written.  Same bits as xmem_copy_channels + three xmem_area_downsample calls. */
+int xmem_hidden_update_gather(const float* g16, int c16, const float* g8, int c8, const float* g4, int c4, const float* logits,
+                              float* out, int ldout, int K, int h, int w, void* stream);
+
 /* CBAM (model/cbam.py:21-77) on g [B][P=H*W][C] and the residual add of FeatureFusionBlock
  * (modules.py:36-39): out = g + CBAM(g).  mlp weights as in the checkpoint: w1 [C/16][C], b1, w2 [C][C/16], b2;
  * spatial 7x7 conv weight sw [2][7][7] (channel 0 = max, 1 = mean), bias sb[1].

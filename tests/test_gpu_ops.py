@@ -258,6 +258,30 @@ def test_copy_channels_broadcast():
     close(dst, ref, 0, 0, 'copy_channels')
 
 
+@pytest.mark.parametrize('shape', [(1, 30, 54, 512, 256, 256), (3, 5, 7, 16, 8, 12), (2, 9, 4, 4, 4, 4)])
+def test_hidden_update_gather_is_the_four_launches_in_one(shape):
+    """HiddenUpdater's concatenated input [g16 | area2(g8) | area4(g4) | area4(logits)] (model/modules.py:49-57) from ONE launch: the
+    same bits as copy_channels + three area_downsample calls, F.interpolate(mode='area') within rounding, padding channels untouched."""
+    from xmem2_amd import ops
+    K, h, w, c16, c8, c4 = shape
+    g16 = torch.randn(K, h, w, c16, generator=g_(11)).cuda(); g8 = torch.randn(K, 2 * h, 2 * w, c8, generator=g_(12)).cuda()
+    g4 = torch.randn(K, 4 * h, 4 * w, c4, generator=g_(13)).cuda(); lg = torch.randn(K, 4 * h, 4 * w, 1, generator=g_(14)).cuda()
+    ld = (c16 + c8 + c4 + 1 + 3) // 4 * 4 + 4
+    a = torch.full((K, h, w, ld), 7.0).cuda(); b = a.clone()
+    ops.hidden_update_gather(g16, g8, g4, lg, a)
+    ops.copy_channels(g16, b, 0)
+    ops.area_downsample(g8, 2, out=b, out_ld=ld, out_off=c16)
+    ops.area_downsample(g4, 4, out=b, out_ld=ld, out_off=c16 + c8)
+    ops.area_downsample(lg, 4, out=b, out_ld=ld, out_off=c16 + c8 + c4)
+    assert torch.equal(a, b), f'max |diff| {float((a - b).abs().max()):.3e}'
+    n = c16 + c8 + c4 + 1
+    assert bool((a[..., n:] == 7.0).all())
+    ref = torch.cat([g16.permute(0, 3, 1, 2), F.interpolate(g8.permute(0, 3, 1, 2), scale_factor=0.5, mode='area'),
+                     F.interpolate(g4.permute(0, 3, 1, 2), scale_factor=0.25, mode='area'),
+                     F.interpolate(lg.permute(0, 3, 1, 2), scale_factor=0.25, mode='area')], 1)
+    close(nchw(a)[:, :n], ref.cpu(), 1e-5, 1e-6, 'hidden_update_gather')
+
+
 @pytest.mark.parametrize('B', [1, 2])
 def test_cbam_residual(B, synth_sd, ref_net):
     from xmem2_amd import ops

@@ -211,6 +211,70 @@ extern "C" int xmem_copy_channels(const float* src, int ldsrc, int srcB, float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// HiddenUpdater input in ONE launch (model/modules.py:49-57, group_modules.py:15-23):
+//   out[k][y][x] = [ g16 | area2(g8) | area4(g4) | area4(logits) ]      (channels; the caller keeps what follows them zero)
+// the concatenated input of the fused g16 / g8 / g4 pointwise convolution.  It used to be four launches per frame (one channel copy, three
+// area downsamples of one float per thread: 9-15 us each in the stream for 36 MB of reads).  One float4 group of the output per thread; the
+// window sums run in area_down_kernel's order (rows, then columns, then one multiply by 1 / r^2): the same bits.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hidden_gather_kernel(const float* __restrict__ g16, int c16, const float* __restrict__ g8, int c8,
+                                                            const float* __restrict__ g4, int c4, const float* __restrict__ logits,
+                                                            float* __restrict__ out, int ldout, int K, int h, int w) {
+    const int n16 = c16 >> 2, n8 = c8 >> 2, n4 = c4 >> 2, G = n16 + n8 + n4 + 1;
+    const size_t total = (size_t)K * h * w * G;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        int g = (int)(e % G);
+        size_t pix = e / G;
+        const int x = (int)(pix % w); const size_t ky = pix / w;          // ky = k * h + y
+        float* const o = out + pix * ldout;
+        if (g < n16) {
+            st4(o + 4 * g, ld4(g16 + pix * c16 + 4 * g));
+        } else if (g < n16 + n8) {
+            g -= n16;
+            const float* src = g8 + ((2 * ky) * (size_t)(2 * w) + 2 * x) * c8 + 4 * g;
+            const size_t row = (size_t)(2 * w) * c8;
+            const f32x4 a = ld4(src), b = ld4(src + c8), c = ld4(src + row), d = ld4(src + row + c8);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            s += a; s += b; s += c; s += d;
+            st4(o + c16 + 4 * g, s * 0.25f);
+        } else if (g < n16 + n8 + n4) {
+            g -= n16 + n8;
+            const float* src = g4 + ((4 * ky) * (size_t)(4 * w) + 4 * x) * c4 + 4 * g;
+            const size_t row = (size_t)(4 * w) * c4;
+            f32x4 v[16];
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) v[4 * dy + dx] = ld4(src + dy * row + (size_t)dx * c4);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += v[i];
+            st4(o + c16 + c8 + 4 * g, s * 0.0625f);
+        } else {
+            const float* src = logits + (4 * ky) * (size_t)(4 * w) + 4 * x;      // one channel: a pixel row is 4 w floats
+            float s = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy) {
+                const f32x4 r = ld4(src + (size_t)dy * (4 * w));                  // 4 x is a multiple of 4 floats: aligned
+                s += r.x; s += r.y; s += r.z; s += r.w;
+            }
+            o[c16 + c8 + c4] = s * 0.0625f;
+        }
+    }
+}
+
+extern "C" int xmem_hidden_update_gather(const float* g16, int c16, const float* g8, int c8, const float* g4, int c4, const float* logits,
+                                         float* out, int ldout, int K, int h, int w, void* stream) {
+    if (!g16 || !g8 || !g4 || !logits || !out || K <= 0 || h <= 0 || w <= 0 || c16 <= 0 || c8 <= 0 || c4 <= 0) return XMEM_ERR_BAD_ARG;
+    if (c16 % 4 || c8 % 4 || c4 % 4 || ldout % 4 || ldout < c16 + c8 + c4 + 1) return XMEM_ERR_UNSUPPORTED;
+    if (((uintptr_t)g16 | (uintptr_t)g8 | (uintptr_t)g4 | (uintptr_t)logits | (uintptr_t)out) & 15) return XMEM_ERR_UNSUPPORTED;
+    const size_t total = (size_t)K * h * w * ((c16 + c8 + c4) / 4 + 1);
+    hipLaunchKernelGGL(hidden_gather_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g16, c16, g8, c8, g4, c4, logits, out,
+                       ldout, K, h, w);
+    return xmem_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // CBAM + residual:  out = g + SpatialGate(ChannelGate(g))
 //   1. channel_pool:   avg / max over the P pixels per (b, c)            -> pooled partials   (kernel 1: needs all pixels)
 //   2. channel_mlp:    cscale = sigmoid(mlp(avg) + mlp(max))

@@ -67,6 +67,7 @@ class XMem:
         # has no idle share for a fourth queue, and the fork / join edges serialise the captured graph.  Off (XMEM_BRANCH_OVERLAP=1 enables).
         self.branch_overlap = os.environ.get('XMEM_BRANCH_OVERLAP', '0') != '0'
         self.fuse_hidden_update = os.environ.get('XMEM_FUSE_HIDDEN_UPDATE', '1') != '0'   # the three pointwise convolutions of HiddenUpdater as one (A/B knob)
+        self.gather_hidden_input = os.environ.get('XMEM_GATHER_HIDDEN_INPUT', '1') != '0'  # ... and their concatenated input built by one launch (A/B knob)
         self._branch = None
         # scratch of the side-stream key-encoder stages is scoped to this instance and released with it
         self._scope = ops.new_scope()
@@ -657,10 +658,13 @@ class XMem:
             if gf is not None and g4d.shape[3] == gf.cin and g4d.dtype == torch.float32:
                 # one pointwise convolution over [g16 | area(g8) | area(g4), area(logits)] (see _upload)
                 c16, c8, ld = g16.shape[3], g8.shape[3], g4d.shape[3]
-                ops.copy_channels(g16, g4d, 0)
-                ops.area_downsample(g8, 2, out=g4d, out_ld=ld, out_off=c16)
-                ops.area_downsample(g4, 4, out=g4d, out_ld=ld, out_off=c16 + c8)
-                ops.area_downsample(logits, 4, out=g4d, out_ld=ld, out_off=c16 + c8 + c4)
+                if self.gather_hidden_input and all(t.is_contiguous() for t in (g16, g8, g4, logits)):
+                    ops.hidden_update_gather(g16, g8, g4, logits, g4d)        # one launch (round 6; the same bits as the four below)
+                else:
+                    ops.copy_channels(g16, g4d, 0)
+                    ops.area_downsample(g8, 2, out=g4d, out_ld=ld, out_off=c16)
+                    ops.area_downsample(g4, 4, out=g4d, out_ld=ld, out_off=c16 + c8)
+                    ops.area_downsample(logits, 4, out=g4d, out_ld=ld, out_off=c16 + c8 + c4)
                 mid = gf.cout
                 cat = torch.empty((K, h, w, mid + hd), dtype=ops.act_dtype(), device=g4.device)
                 ops.conv2d(g4d, gf, out=cat, out_ld=cat.shape[3])

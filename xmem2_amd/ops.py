@@ -815,6 +815,20 @@ def copy_channels(src, dst, dst_off, c=None, src_off=0):
     return dst
 
 
+def hidden_update_gather(g16, g8, g4, logits, out):
+    """out[..., :c16+c8+c4+1] = [g16 | area2(g8) | area4(g4) | area4(logits)] in one launch (float32 NHWC; HiddenUpdater's input,
+    model/modules.py:49-57); the same bits as copy_channels + three area_downsample calls."""
+    K, h, w, c16 = g16.shape
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (g16, g8, g4, logits, out)):
+        raise RuntimeError('hidden_update_gather: contiguous float32 tensors only')
+    if tuple(g8.shape[:3]) != (K, 2 * h, 2 * w) or tuple(g4.shape[:3]) != (K, 4 * h, 4 * w) or tuple(logits.shape) != (K, 4 * h, 4 * w, 1) \
+            or tuple(out.shape[:3]) != (K, h, w):
+        raise RuntimeError('hidden_update_gather: shapes do not belong to one decoder pass')
+    check(load().xmem_hidden_update_gather(ptr(g16), c16, ptr(g8), g8.shape[3], ptr(g4), g4.shape[3], ptr(logits), ptr(out), out.shape[3],
+                                           K, h, w, stream_ptr()))
+    return out
+
+
 def cbam_residual(g, p):
     """out = g + CBAM(g); p = dict(w1,b1,w2,b2,sw,sb) device tensors (float32); g float32 or float16."""
     lib = load()
