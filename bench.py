@@ -921,8 +921,9 @@ def main():
             'roofline': {'bound': 'mfma',
                          'kernel': 'affinity_filter16_kernel<false, 4|8> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
                                    'of model/memory_util.py:7-39 on v_mfma_f32_32x32x16_f16 with augmented fp16 operands (the result is a rigorous '
-                                   'UPPER estimate; one candidate bit per memory row x query).  Around it in the same call: bound from the previous '
-                                   'frame\'s matches, scan of the bit matrix, [tighten + second filter / scan pass over query tiles whose lists '
+                                   'UPPER estimate; one candidate bit per memory row x query, and since round 6 the kernel turns its bits into the per-query '
+                                   'candidate lists itself - no bit matrix, no scan kernel).  Around it in the same call: bound from the previous '
+                                   'frame\'s matches, [tighten + second filter pass over query tiles whose lists '
                                    'overflowed], exact fp32 refine of the listed candidates - outputs bit-identical to the fp32 MFMA select',
                          'note': 'achieved = SURVEY 8(d) algorithmic FLOPs of the similarity (F_sim = 4*C_k*N*HW per call) / the average duration of '
                                  'THIS kernel (since round 6 it runs on the readout stream UNDER the previous frame\'s decoder - early readout is the '
@@ -1002,7 +1003,7 @@ def main():
                                                      'or 1/4 of those FLOPs), not a roofline fraction'}
                 if aff_us:
                     line['roofline']['timed_region_trace_us_per_frame'] = aff_us
-                    # the SELECT as a whole (every launch of the call: bound, filter, scan / lists, refine) against the pipe its contraction runs on
+                    # the SELECT as a whole (every launch of the call: bound, filter + lists, [pass 2], refine) against the pipe its contraction runs on
                     line['roofline']['call_frac'] = (aff_gf / (aff_us * 1e-3)) / PEAK_F16_MFMA_TFLOPS
                     line['roofline']['call_tflops'] = aff_gf / (aff_us * 1e-3)
                     line['roofline']['frac_fp32_equivalent_from_trace'] = (aff_gf / (aff_us * 1e-3)) / PEAK_FP32_MFMA_TFLOPS

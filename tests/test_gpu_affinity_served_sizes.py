@@ -1,9 +1,10 @@
 """The readout pipeline that serves every frame after the first (xmem_affinity_topk_hinted: bound from a hint -> fp16 filter
--> scan -> [tighten -> second pass] -> exact fp32 refine) at the sizes the BASELINE configurations run it at:
+(which emits the per-query candidate lists itself)
+-> [tighten -> second pass] -> exact fp32 refine) at the sizes the BASELINE configurations run it at:
 
     B32  N = 51 840   x HW = 1 620   (list capacity 2 048,  13 query tiles)
-    C4   N = 921 600  x HW = 3 600   (list capacity 16 384, 29 query tiles, 10.4 M-word bit matrix)
-    C5   N = 4 177 920 x HW = 8 160  (list capacity 16 384, 64 query tiles, 4.3 GB bit matrix)
+    C4   N = 921 600  x HW = 3 600   (list capacity 16 384, 29 query tiles)
+    C5   N = 4 177 920 x HW = 8 160  (list capacity 16 384, 64 query tiles; rounds 2-5: a 4.3 GB bit matrix)
 
 For every size: the hinted result must equal the un-hinted call (fp32 MFMA select) BIT FOR BIT for a perfect hint, a hint
 shifted by one grid cell, a garbage hint (no bound: every pair is a candidate, every list overflows, the tighten pass
