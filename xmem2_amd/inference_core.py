@@ -357,7 +357,7 @@ class InferenceCore:
         h, w, K = f16.shape[1], f16.shape[2], hidden.shape[0]
         main = torch.cuda.current_stream()
         if self._ro_stream is None:
-            self._ro_stream = _net_stream(net, 'readout', lambda: torch.cuda.Stream(device=net.device))
+            self._ro_stream = _net_stream(net, 'readout', lambda: ops.readout_stream(net.device))
         if after is None:
             after = torch.cuda.Event()
             after.record(main)

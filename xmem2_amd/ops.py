@@ -769,6 +769,14 @@ def side_stream(device):
     return masked_stream(device, n) if n > 0 else torch.cuda.Stream(device=device)
 
 
+def readout_stream(device):
+    """The stream the early readout (the NEXT hinted frame's select + readout) runs on, under the current frame's decoder.
+    XMEM_READOUT_PRIORITY (tools: A/B) = the stream's priority: -1 high (its short chain of kernels is dispatched ahead of the decoder's
+    as CUs free up), 0 normal."""
+    pr = int(os.environ.get('XMEM_READOUT_PRIORITY', '0') or 0)
+    return torch.cuda.Stream(device=device, priority=pr)
+
+
 def trace_marker(tag=0):
     """Empty kernel `xmem_trace_marker_kernel` on the current stream: cuts a rocprofv3 kernel trace to a region."""
     check(load().xmem_trace_marker(int(tag), stream_ptr()))
