@@ -260,10 +260,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? F16_WG_PER_CU : 1) void affinity
     // entry = halfword of 16 pair bits | filter lane << 16 | query block << 22 | (tile - tbase) << 23.  The buffer belongs to ONE wave:
     // its fill count is a scalar, a push is a ballot, a prefix count and an LDS write that nothing waits for.  drain(): one lane per
     // entry, ONE atomic reserves the halfword's slots in its query's list (bit 15 - r of lane l <-> row 32 (t - tile0) + (r & 3) +
-    // 8 (r >> 2) + 4 (l >> 5), query 32 b + (l & 31)); afterwards every lane looks at its own queries' counters: a list that is full
-    // (after a scene cut nearly every bit is set) takes no more pushes, so a hopeless pass costs lcap entries per query, not N.
+    // 8 (r >> 2) + 4 (l >> 5), query 32 b + (l & 31)); a list that the atomic finds at its capacity closes its query for the wave
+    // (after a scene cut nearly every bit is set: a hopeless pass costs about lcap entries per query, not N).
     // The buffer lives in the PAD of the staged rows: bytes 288 .. 303 of a 304-byte LDS row are neither written by the stash nor read
     // by the fragment loads; entry j of wave w is dword j & 3 of the pad of row 64 w + (j >> 2) (rows of both stages, numbered through).
+    static_assert(F16_LDB == F16_K * 2 + 16, "the candidate buffer is the 16 pad bytes behind the 288 operand bytes of a staged row");
+    static_assert(F16_WB == 63 * 4 && F16_DU * 64 >= F16_WB, "63 rows x 4 dwords of entries (the 64th row's pad is the closed-list table); one drain trip takes a full buffer");
+    static_assert(F16_WB_TSPAN + 8 < 512, "9 bits of an entry carry its tile relative to the buffer's base tile");
     unsigned char* const wb = &Ah[0][0] + (size_t)wave * 64 * F16_LDB + 288;
     auto wb_at = [&](int j) -> unsigned* {                       // (24-bit multiply-add: full rate; the 32-bit multiply is a quarter-rate instruction)
         return reinterpret_cast<unsigned*>(wb + __umul24((unsigned)j >> 2, (unsigned)F16_LDB) + ((unsigned)j & 3u) * 4u);
