@@ -537,6 +537,71 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs p) {
     }
 }
 
+// The mask head proper (3x3, stride 1, 256 -> 1 at 1/4 resolution, fp32): one wave per FOUR neighbouring output pixels of a row.  With a
+// wave per pixel every wave fetched its own 3 x 3 input vectors and the nine weight vectors: 18 KB through the vector cache for 1 KB of
+// new input - 466 MB per launch, 20 us for 60 MFLOP.  Four pixels share a 3 x 6 patch and one set of weights: 27 KB per four pixels
+// (3.4x fewer bytes through the cache).  Per pixel the products and the order of the additions are those of conv_cout1_kernel: same bits.
+static bool cout1_row4() { static const bool on = !(getenv("XMEM_COUT1_ROW4") && getenv("XMEM_COUT1_ROW4")[0] == '0'); return on; }   // tools: A/B
+__global__ __launch_bounds__(256) void conv_cout1_row4_kernel(ConvArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int gpr = (p.Wo + 3) >> 2;                              // groups of four pixels per output row
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= p.B * p.Ho * gpr) return;
+    const int g = wid % gpr, row = wid / gpr;                     // row = b * Ho + oh
+    const int oh = row % p.Ho, b = row / p.Ho;
+    const int ow0 = 4 * g;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c = lane * 4;
+    if (c < p.Cin) {
+        f32x4 xv[3][6], wv[9];
+        bool okr[3], okc[6];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) okc[cc] = (unsigned)(ow0 - p.pad + cc) < (unsigned)p.W;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh - p.pad + r;
+            okr[r] = (unsigned)ih < (unsigned)p.H;
+            const int ihc = min(max(ih, 0), p.H - 1);
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {                      // unconditional loads from clamped coordinates, all requested together
+                const int iwc = min(max(ow0 - p.pad + cc, 0), p.W - 1);
+                xv[r][cc] = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(b * p.H + ihc) * p.W + iwc) * p.ldin + c);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.Cin + c);
+        if (p.relu_in) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    f32x4& x = xv[r][cc];
+                    x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, cc = j + t % 3;
+                if (!(okr[r] && okc[cc])) continue;               // a padding tap
+                const f32x4 x = xv[r][cc];
+                acc[j] = fmaf(x.x, wv[t].x, acc[j]); acc[j] = fmaf(x.y, wv[t].y, acc[j]);
+                acc[j] = fmaf(x.z, wv[t].z, acc[j]); acc[j] = fmaf(x.w, wv[t].w, acc[j]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+    if (lane < 4 && ow0 + lane < p.Wo) {
+        const float a = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+        const int m = row * p.Wo + ow0 + lane;
+        float v = a * p.scale[0] + p.shift[0];
+        if (p.res) v += p.res[(size_t)(p.res_mod ? m % p.res_mod : m) * p.ldres];
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        p.out[(size_t)m * p.ldout] = v;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions (85 % of the network's FLOPs):
 //   Y = A^T [ (G g G^T) .* (B^T d B) ] A      (Lavin & Gray) - 16 multiplies per 2x2 outputs instead of 36.
@@ -1533,10 +1598,13 @@ extern "C" int xmem_conv2d_nhwc(const xmem_conv_desc* d, void* workspace, size_t
         return gemm_stream_launch(g, pl.sv, pl.sring, s);
     }
     if (pl.bm == 0) {
-        // (a variant with eight output pixels of a row per wave - 3.75 instead of 9 fetches of every input row - measured 28.0 us
-        // against 24.9 us for this one-pixel-per-wave form at the 480p mask head: the kernel is bound by its wave reductions and
-        // load latency, not by the L2 reads; removed)
+        // (round 4: a variant with EIGHT output pixels of a row per wave measured 28.0 us against 24.9 us for the one-pixel-per-wave form at
+        // the 480p mask head - its taps were fetched one after the other behind their bounds branches.  Round 6, with every load of a wave
+        // requested together: four pixels per wave 26.8 us against 31.2 (host-side events, same bits), +0.6 % on the B32 line; small maps
+        // (2 x 37 x 51: 21 against 16 us) keep one pixel per wave - too few waves otherwise)
         if (half) hipLaunchKernelGGL(conv_cout1_kernel<true>, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
+        else if (cout1_row4() && a.M >= 8192 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.Cin <= 256 && a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2)
+            hipLaunchKernelGGL(conv_cout1_row4_kernel, dim3(cdiv(a.B * a.Ho * ((a.Wo + 3) / 4), 4)), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_cout1_kernel<false>, dim3(cdiv(a.M, 4)), dim3(256), 0, s, a);
         return xmem_check_launch();
     }
