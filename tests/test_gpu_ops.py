@@ -51,6 +51,8 @@ CONV_CASES = [
     (2, 6, 10, 512, 512, 3, 1, 1, False, False, True, False),      # conv2 + residual
     (1, 30, 54, 1024, 129, 3, 1, 1, False, False, False, False),   # key projection (Cout=129)
     (2, 24, 40, 256, 1, 3, 1, 1, True, False, False, False),       # pred (Cout=1, relu_in)
+    (1, 95, 101, 256, 1, 3, 1, 1, True, False, False, False),      # pred on a map of >= 8192 pixels: four pixels per wave, ragged row tail
+    (2, 80, 64, 192, 1, 3, 1, 1, False, True, True, False),        # the same kernel with fewer channels than lanes x 4, residual, relu_out
     (2, 6, 10, 260, 256, 1, 1, 0, False, False, True, False),      # g4_conv (generic K, residual chain)
     (1, 60, 108, 256, 256, 3, 1, 1, True, True, False, False),     # decoder up_8_4-like, 128x128 tiles
     (3, 15, 27, 576, 192, 3, 1, 1, False, False, False, False),    # GRU transform, odd spatial size
