@@ -17,7 +17,10 @@ else:
     ops._plans = {} if os.environ.get('XMEM_RETUNE_ALL') else ops._load_plans()   # default: keep shipped plans, add new shapes
 net = XMem(dict(bench.b32_config(), precision=PREC), None).to('cuda').eval(); net.load_weights(synthetic_state_dict(0))
 net.use_graphs = False
-for (H, W, K) in [(480, 854, 1), (480, 854, 2), (480, 854, 3), (720, 1280, 1), (240, 427, 1), (240, 427, 2), (1080, 1920, 1)]:
+GEOMS = [(480, 854, 1), (480, 854, 2), (480, 854, 3), (720, 1280, 1), (240, 427, 1), (240, 427, 2), (1080, 1920, 1)]
+if os.environ.get('XMEM_TUNE_GEOMS'):            # e.g. "1080x1920x5,1080x1920x3,720x1280x2": more (resolution, objects) pairs - config 5 is 1080p x 5 objects
+    GEOMS = [tuple(int(v) for v in g.split('x')) for g in os.environ['XMEM_TUNE_GEOMS'].split(',')]
+for (H, W, K) in GEOMS:
     cfg = bench.b32_config(); cfg['mem_every'] = 2
     fr = torch.from_numpy(synthetic_frames(4, H, W)).cuda(); mk = torch.from_numpy(synthetic_masks(4, K, H, W)).cuda()
     core = InferenceCore(net, cfg); core.set_all_labels(list(range(1, K + 1)))
