@@ -21,9 +21,10 @@ inside a second, instrumented pass of the timed schedule and (ii) a rocprofv3 --
 a child process and cut to the timed region with marker kernels (N=1, rank 0).
 
 Frame pipeline of `value` (optional for a caller, changes no result): the key encoder of the coming frames in batches of --key-batch on
-a side stream (`prefetch_keys`), readout + decoder + mask output on the main stream.  XMEM_EARLY_READOUT=1 additionally runs the memory
-readout of the next prefetched frame on a third stream under the current frame's decoder (opt-in: DESIGN.md 4.7; `config.early_readout`
-says whether a line used it).
+a side stream (`prefetch_keys`), the memory readout of the next prefetched frame on a third stream under the current frame's decoder
+(early readout, the default since round 6: DESIGN.md 4.7; `config.early_readout` says whether a line used it; XMEM_EARLY_READOUT=0 turns
+it off), decoder + mask output on the main stream.  The timed region is self-contained: nothing of its frames is computed before the
+clock starts (the warm-up's pending hints are dropped, the region hints its own first key batch) and every mask is on the host before it stops.
 `value_no_prefetch` is the same workload through `step()` alone - the reference's call sequence.
 """
 import argparse
@@ -59,7 +60,8 @@ F16_K = 144                            # contraction length of the fp16 filter (
 CK, CV, TOPK = 64, 512, 30
 CLEAR_MARGIN = 2e-2                    # the tests' gate (tests/test_gpu_e2e.py): 2x the reference's own 8-vs-1-thread probability noise
 TIGHT_MARGIN = 2e-3                    # SURVEY 8(c)'s acceptance margin, reported beside it
-SCHEMA = 5                             # meaning of the keys of the JSON line; see `schema_note` in the line
+SCHEMA = 6                             # meaning of the keys of the JSON line; see `schema_note` in the line
+LONG_WINDOW = 200                      # frames of `value_long_window` (reported when --steps is shorter)
 BASELINE_METRIC = 'frames/sec at 480p, 1 obj, 32 memory frames; mask IoU vs reference'
 
 PRECISION_LABEL = {'fp32': '',
@@ -228,19 +230,19 @@ def run_gpu(args, device, rank, world):
 
     host_t = {'step': 0.0, 'hint': 0.0, 'fetch': 0.0, 'n': 0} if os.environ.get('XMEM_BENCH_HOST_TIMES') else None
 
-    def one_step(i, stop=None):
-        # `stop`: one past the last frame of the stream being driven.  A finite stream does not hint past its end (run_on_video does
-        # not either): the batch-4 key pass of frames nobody will step is 3.7 ms of side-stream work that the closing device sync
-        # would wait for - 6 % of a 20-frame timed region (round 6; invisible at 200 frames).
+    def one_step(i, stop=None, origin=0):
+        # `stop`: one past the last frame of the stream being driven; `origin`: its first frame (the phase of the key batches).  A finite
+        # stream does not hint a batch that starts at or past its end (run_on_video does not either); a batch that straddles the end is
+        # hinted whole (no new graph variant inside a timed region - the frames past the end are extra work INSIDE it).
         if host_t is None:
             prob = core.step(frame(i), None, None)
-            if i % KB == 0 and (stop is None or i + KB < stop):   # first frame of its batch consumed: hint the next batch under it
+            if (i - origin) % KB == 0 and (stop is None or i + KB < stop):   # first frame of its batch consumed: hint the next batch under it
                 hint(i + KB)
             return [m for _, m in fetcher.submit(i, ops.argmax_u8(prob))]
         t0 = time.perf_counter()
         prob = core.step(frame(i), None, None)
         t1 = time.perf_counter()
-        if i % KB == 0 and (stop is None or i + KB < stop):
+        if (i - origin) % KB == 0 and (stop is None or i + KB < stop):
             hint(i + KB)
         t2 = time.perf_counter()
         am = ops.argmax_u8(prob)
@@ -248,7 +250,7 @@ def run_gpu(args, device, rank, world):
         out = [m for _, m in fetcher.submit(i, am)]
         t3 = time.perf_counter()
         host_t['step'] += t1 - t0; host_t['hint'] += t2 - t1; host_t['fetch'] += t3 - t2; host_t['n'] += 1
-        host_t.setdefault('by_phase', {}).setdefault(i % KB, []).append((t1 - t0, t2 - t1, t2b - t2, t3 - t2b))
+        host_t.setdefault('by_phase', {}).setdefault((i - origin) % KB, []).append((t1 - t0, t2 - t1, t2b - t2, t3 - t2b))
         return out
 
     # setup (untimed, like the preload): enough frames to capture every HIP graph variant the stream will replay
@@ -260,6 +262,13 @@ def run_gpu(args, device, rank, world):
         one_step(i)
     for i in range(args.warmup):
         one_step(i)
+    # Nothing of the timed frames is computed before the clock starts (schema 6): the warm-up's hints reach into them (its last batches were
+    # hinted under its last frames, and the last warm-up step enqueued the first timed frame's memory readout ahead) - all of that is dropped
+    # here, and the timed region starts like a stream of its own: its first key batch is hinted INSIDE it, un-overlapped, its first frame
+    # reads the memory inside its own step().  Until round 6 the first timed batch's key pass ran during the warm-up: with the closing
+    # hint past the end removed (round 6, step 12) the region then held one key pass (of K / key_batch) less than its K frames need.
+    # (The dropped readout leaves only its top-k as the next call's HINT, which changes no result - xmem_affinity_topk_hinted.)
+    core.cancel_prefetch()
     fetcher.drain()
     # ---- timed region: exactly `steps` frames, barrier + device sync on both sides --------------------------
     barrier(device); torch.cuda.synchronize(device)
@@ -267,8 +276,10 @@ def run_gpu(args, device, rank, world):
         ops.trace_marker(1)
     t0 = time.perf_counter()
     out_masks = []
+    first = args.warmup
+    hint(first)
     for i in range(args.steps):
-        out_masks += one_step(args.warmup + i, stop=args.warmup + args.steps)
+        out_masks += one_step(first + i, stop=first + args.steps, origin=first)
     out_masks += [m for _, m in fetcher.drain()]      # every mask of the timed steps is on the host before the clock stops
     assert len(out_masks) == args.steps
     if args.traced_child:
@@ -285,19 +296,39 @@ def run_gpu(args, device, rank, world):
             print(f"   frame i%KB={ph}: median host ms  step {med[0]:.3f}  hint {med[1]:.3f}  argmax launch {med[2]:.3f}  submit/wait {med[3]:.3f}", file=sys.stderr)
     m = core.memory
     n_elems = m.temporary_work_mem.size + m.permanent_work_mem.size + m.long_mem.size
+    # ---- the same measurement over a LONG window (N = 1, when `steps` is short): a self-contained region starts with its first key batch
+    # un-overlapped (3.3 ms on an idle chip before the first decoder can run: 10 % of a 20-frame region, 1 % of a 200-frame one); the
+    # reference's metric is the rate of a whole video (run_on_video.py:106-113,143), so the line also carries it at LONG_WINDOW frames -
+    # measured exactly like `value` (nothing pending before, own first hint inside, every mask on the host before the clock stops)
+    long_window = None
+    if rank == 0 and world == 1 and not args.traced_child and not args.scale_only and args.steps < LONG_WINDOW \
+            and not os.environ.get('XMEM_BENCH_SKIP_PASSES'):
+        first = args.warmup + args.steps
+        core.cancel_prefetch(); fetcher.drain()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        hint(first)
+        got = 0
+        for i in range(LONG_WINDOW):
+            got += len(one_step(first + i, stop=first + LONG_WINDOW, origin=first))
+        got += len(fetcher.drain())
+        torch.cuda.synchronize(device)
+        long_window = dict(value=LONG_WINDOW / (time.perf_counter() - t1), steps=LONG_WINDOW)
+        assert got == LONG_WINDOW
     # ---- instrumented pass (rank 0): the SAME schedule again (graphs, two streams, batched hints) with HIP events on
     # the launch stream around the memory-readout calls, which are eager launches between the captured stages
     taps, inst_frames, inst_elapsed = {}, 0, None
     skip_extra = bool(os.environ.get('XMEM_BENCH_SKIP_PASSES'))            # debugging aid: none of the instrumented passes
     if rank == 0 and not args.traced_child and not args.scale_only and not skip_extra:
         inst_frames = min(args.steps, 100)
-        hint((args.warmup + args.steps + KB - 1) // KB * KB)          # (the timed stream ended without a hint past its end: resume them)
+        start = args.warmup + args.steps + (LONG_WINDOW if long_window else 0)
+        core.cancel_prefetch()                                        # (frames a straddling last batch hinted past the end of the timed stream)
+        hint(start)                                                   # the timed stream ended without a hint past its end: resume them
         ops.EVENT_TAP = []
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
-        start = args.warmup + args.steps
         for i in range(inst_frames):
-            one_step(start + i)
+            one_step(start + i, origin=start)
         fetcher.drain()
         torch.cuda.synchronize(device)
         inst_elapsed = time.perf_counter() - t1
@@ -321,6 +352,7 @@ def run_gpu(args, device, rank, world):
         ms, lens, flagged, tiles = [], [], 0, 0
         start = args.warmup + args.steps + inst_frames
         start = (start + KB - 1) // KB * KB
+        core.cancel_prefetch()
         hint(start)
         offs = [C.c_size_t(), C.c_size_t(), C.c_size_t()]
         hw = (padded(wl['H']) // 16) * (padded(wl['W']) // 16)
@@ -356,17 +388,19 @@ def run_gpu(args, device, rank, world):
                         query_tiles_needing_second_pass=flagged / max(tiles, 1),
                         note='final list length per query after the readout (after the second pass where it ran); '
                              'fraction of 128-query tiles whose lists overflowed in pass 1')
-    # ---- what the convolutions of one frame EXECUTE on the matrix pipe: one hint batch + KB frames of the same schedule run
-    # eagerly with ops.RECORD on (every conv2d call notes its shape, plan, algorithmic FLOPs and the MFMA FLOPs that plan issues:
-    # direct form padded to its tile, F(2x2) 16 / F(4x4) 36 position GEMMs); not part of any reported rate
+    # ---- what the convolutions of one frame EXECUTE on the matrix pipe: KB frames run eagerly with ops.RECORD on (every conv2d call notes
+    # its shape, plan, algorithmic FLOPs and the MFMA FLOPs that plan issues: direct form padded to its tile, F(2x2) 16 / F(4x4) 36
+    # position GEMMs).  Recording runs everything eagerly and un-hinted (`prefetch_keys` is a pass-through while ops.eager_only()): every
+    # recorded frame carries its own key encoder, its select and its decoder - nothing may be pending from the passes above, or the
+    # recorded frames would consume keys encoded un-recorded.  Not part of any reported rate
     conv_survey = None
     if rank == 0 and not args.traced_child and not args.scale_only and not skip_extra:
         start = ((args.warmup + args.steps + inst_frames + 400) // KB + 1) * KB
-        hint(start)                                                  # consumed by the recorded frames; ITS convolutions are not recorded
+        core.cancel_prefetch()
         ops.RECORD = []
         try:
             for j in range(KB):
-                one_step(start + j)                                  # the first one issues (and records) the next hint batch
+                one_step(start + j)
             fetcher.drain(); torch.cuda.synchronize(device)
         finally:
             recs, ops.RECORD = ops.RECORD, None
@@ -433,7 +467,7 @@ def run_gpu(args, device, rank, world):
     return dict(elapsed=elapsed, preload_s=preload_s, taps=taps, inst_frames=inst_frames, inst_elapsed=inst_elapsed,
                 masks=out_masks, core=core, frames=frames, masks_in=masks, sd=sd, n_query=n_query, base=base,
                 n_elems=n_elems, wl=wl, cfg=cfg, filter_events=filt, candidates=cand, plain=plain, frame_fn=frame,
-                conv_survey=conv_survey, select_alone=select_alone)
+                conv_survey=conv_survey, select_alone=select_alone, long_window=long_window)
 
 
 # ---- rocprofv3 kernel trace of the timed region (child process) ------------------------------------------------
@@ -530,8 +564,11 @@ def run_mode_child(args, mode):
     try:
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         j = json.loads(p.stdout.strip().splitlines()[-1])
-        return dict(value=j['value'], unit='frames/s', steps=steps, dtype=j['dtype'],
-                    note='opt-in mode, separately reported, not the headline: ' + PRECISION_LABEL[mode].strip())
+        out = dict(value=j['value'], unit='frames/s', steps=steps, dtype=j['dtype'],
+                   note='opt-in mode, separately reported, not the headline: ' + PRECISION_LABEL[mode].strip())
+        if j.get('value_long_window'):
+            out['value_long_window'] = j['value_long_window']          # the same mode over LONG_WINDOW frames (see the line's own key)
+        return out
     except Exception as e:
         return dict(error=f'{type(e).__name__}: {e}')
 
@@ -946,7 +983,11 @@ def main():
                            'EXECUTED MFMA FLOPs / conv family time / the peak of the pipe the mode runs on (fp32: 157.3 TF; fp16 / fp32x / fp16w modes: 2.5 PF - '
                            'round 4 divided every mode by 157.3); parity.clear_margin = 2e-2 (round 4: 5e-2) and parity.survey_margin = 2e-3.  Round 6, same schema: '
                            'config.early_readout is true (the schedule is the default again: its wrong stream was a caller-side race, DESIGN.md 4.7); the timed '
-                           'stream does not hint frames past its end; cpu_baseline gains threads / host_physical_cores (cores = threads used)',
+                           'stream does not hint frames past its end; cpu_baseline gains threads / host_physical_cores (cores = threads used).  Schema 6 (end of round 6): '
+                           'the timed region is self-contained - the warm-up\'s pending key hints and its readout enqueued ahead are dropped before the clock '
+                           'starts, the first key batch of the timed frames is hinted (un-overlapped) inside the region, key batches are phased from its first '
+                           'frame; before, the first timed batch was encoded during the warm-up, so a region of K frames held K / key_batch - 1 key passes '
+                           '(schema-5 lines of round 6 read ~1 % high at 200 steps and ~7 % high at 20)',
             'roofline': {'bound': 'mfma',
                          'kernel': 'affinity_filter16_kernel<false, 4|8> (pass 1 of xmem_affinity_topk_hinted): the N x HW similarity contraction '
                                    'of model/memory_util.py:7-39 on v_mfma_f32_32x32x16_f16 with augmented fp16 operands (the result is a rigorous '
@@ -984,6 +1025,11 @@ def main():
             'preload_s_per_rank': preload_all,
             'slowest_rank_fps': min(per_rank), 'fastest_rank_fps': max(per_rank),
         }
+        if res.get('long_window'):
+            line['value_long_window'] = res['long_window']['value']
+            line['value_long_window_note'] = (f'frames/s of a {res["long_window"]["steps"]}-frame timed region measured exactly like `value` (self-contained, same '
+                                              'process, right after it): a region starts with its first key batch un-overlapped (~3.3 ms before the '
+                                              f'first decoder can run), which weighs {args.steps} timed frames far more than a video')
         if res.get('plain'):
             # the reference's caller hands step() one frame at a time (inference/run_on_video.py:98-113): the same workload
             # WITHOUT the prefetch_keys extra - the drop-in rate of the unchanged call sequence
@@ -1026,7 +1072,7 @@ def main():
                                              'algorithmic_gflop_per_frame_surveyed': cs['algorithmic_gflop_per_frame'] if cs else None,
                                              'us_per_frame': conv_us, 'traffic': None,
                                              'note': 'achieved / frac = MFMA FLOPs the plans of one frame EXECUTE (direct form padded to its tiles, F(2x2) 16 and F(4x4) 36 '
-                                                     'position GEMMs; surveyed with ops.RECORD over one hint batch + key_batch frames) / the conv family\'s kernel time in the '
+                                                     'position GEMMs; surveyed with ops.RECORD over key_batch eagerly run frames, each with its own key encoder) / the conv family\'s kernel time in the '
                                                      'marker-cut trace of the timed region (GEMMs AND transform kernels) / the fp32 MFMA peak.  algorithmic_* = the DIRECT '
                                                      'convolution\'s FLOPs of SURVEY 8(d) over the same time: a speed figure (it exceeds the peak because Winograd executes 1/2.25 '
                                                      'or 1/4 of those FLOPs), not a roofline fraction'}
