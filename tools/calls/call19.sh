@@ -1,9 +1,12 @@
-#!/bin/bash
-mkdir -p gpurun_out/c19
-O=gpurun_out/c19/filter_ab.txt
-run() { echo "== $*" >> $O; env "$@" timeout 200 python tools/probes/filter_sizes.py c4 c5 2>&1 | grep -v amdgpu.ids >> $O; }
-run XMEM_F16_PIPE=1 XMEM_F16_WAVES=4
-run XMEM_F16_PIPE=1 XMEM_F16_WAVES=4 XMEM_F16_DBG=8 PROBE_NOCHECK=1
-run XMEM_F16_PIPE=1 XMEM_F16_WAVES=4 XMEM_F16_DBG=13 PROBE_NOCHECK=1
-cat $O
-tools/probes/mfma_shadow/lds_feed 16000 2>&1 | head -9 | tail -3
+# the other workload lines re-collected at schema 6 (self-contained timed region)
+mkdir -p gpurun_out/c19 && cd $GRAFT_REPO_ROOT
+bash tools/collect_r06.sh c > gpurun_out/c19/collect.log 2>&1
+tail -8 gpurun_out/c19/collect.log
+python - <<'P'
+import json
+for f in ['b32dyn','c3','b32motion','c4','c5']:
+    try:
+        d=json.loads(open(f'gpurun_out/prof_r06/r06_bench_{f}.json').read().strip().splitlines()[-1])
+        print(f, round(d['value'],1), d['steps'], d.get('value_long_window'), d.get('value_no_prefetch'), d['schema'])
+    except Exception as e: print(f, 'ERR', e)
+P
