@@ -1,12 +1,11 @@
-#!/bin/bash
-mkdir -p gpurun_out/c22
-O=gpurun_out/c22/filter_ab.txt
-run() { echo "== $*" >> $O; env "$@" timeout 200 python tools/probes/filter_sizes.py b32 c4 c5 2>&1 | grep -v amdgpu.ids >> $O; }
-run XMEM_F16_PIPE=1
-run XMEM_F16_PIPE=0
-run XMEM_F16_PIPE=1 XMEM_F16_WAVES=4
-run XMEM_F16_PIPE=0 XMEM_F16_WAVES=4
-run XMEM_F16_PIPE=1 XMEM_F16_DBG=8 PROBE_NOCHECK=1
-run XMEM_F16_PIPE=1 XMEM_F16_DBG=5 PROBE_NOCHECK=1
-run XMEM_F16_PIPE=1 XMEM_F16_DBG=13 PROBE_NOCHECK=1
-cat $O
+mkdir -p gpurun_out/c22 && cd $GRAFT_REPO_ROOT
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/c22/driver_like.json 2> gpurun_out/c22/driver_like.err ) 2> gpurun_out/c22/time.txt
+python - <<'P'
+import json
+d=json.loads(open('gpurun_out/c22/driver_like.json').read().strip().splitlines()[-1])
+print({k:d.get(k) for k in ('value','ms_per_step','steps','warmup','value_long_window','value_no_prefetch','schema')})
+print('roofline', {k:d['roofline'].get(k) for k in ('frac','achieved','traffic','call_frac')}, 'alone', d['roofline'].get('alone',{}).get('frac'))
+print('conv', d['conv_roofline'].get('frac'), 'cpu', d['cpu_baseline'].get('value'), d['cpu_baseline'].get('threads'), d.get('speedup_vs_cpu'))
+print('fp32x', d['value_fp32x'].get('value'), d['value_fp32x'].get('value_long_window'), 'fp16', d['value_fp16_loop'].get('value'), d['value_fp16_loop'].get('value_long_window'))
+P
+cat gpurun_out/c22/time.txt
