@@ -1,7 +1,2 @@
-#!/bin/bash
-mkdir -p gpurun_out/c23
-timeout 900 python -m pytest tests/test_gpu_affinity_served_sizes.py tests/test_gpu_rows16.py tests/test_gpu_stream_b32.py -q -x -m gpu > gpurun_out/c23/pytest.log 2>&1
-tail -3 gpurun_out/c23/pytest.log
-timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -m gpu -k "affinity or readout or memory" >> gpurun_out/c23/pytest.log 2>&1
-tail -3 gpurun_out/c23/pytest.log
-timeout 200 python tools/probes/filter_sizes.py b32 c4 c5 2>&1 | grep -v amdgpu.ids > gpurun_out/c23/filter_sizes.txt; cat gpurun_out/c23/filter_sizes.txt
+mkdir -p gpurun_out/c23 && cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_a*.py tests/test_gpu_b*.py tests/test_gpu_c*.py tests/test_gpu_e2e.py -q -m gpu -x --durations=5 > gpurun_out/c23/t.log 2>&1; tail -14 gpurun_out/c23/t.log
